@@ -1,0 +1,168 @@
+/* msc.h — C-ABI of libmsc_hip.so: the MI355X (gfx950) kernels behind the multimodal
+ * semantic-communication forward/backward path named by BASELINE.json `north_star`.
+ *
+ * Reference interface each entry replaces: NONE EXISTS. /root/reference/README.md:1-2 is the
+ * whole upstream snapshot (SURVEY.md "finding zero", §8b), so there is no plugin/FFI surface to
+ * mirror.  The subsystem names (ImageEncoder / BEV encoder / FusionTransformer / SemanticEncoder /
+ * SemanticDecoder / Channel / policy-value head / DP all-reduce) come from BASELINE.json; each
+ * group below says which of them it serves.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (every entry point):
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless a comment
+ *     says "host"; the caller owns every buffer; nothing here allocates, frees or synchronises.
+ *   - `dtype` selects the storage/MFMA input type of activations and compute copies of weights:
+ *       MSC_F32  = fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)   — parity mode
+ *       MSC_BF16 = bf16 storage, bf16 MFMA with fp32 accumulation           — throughput mode
+ *     statistics, losses, gradients of parameters and optimizer state are always fp32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Work is enqueued only.
+ *   - return value: MSC_OK (0) or a negative MSC_ERR_*; never throws, never prints.
+ *   - activations are channels-last: images/feature maps NHWC, token tensors [B,T,D].
+ *   - conv weights are OHWI = [Cout][KH][KW][Cin]; linear weights are [out][in].
+ */
+#ifndef MSC_H_
+#define MSC_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MSC_F32 = 0, MSC_BF16 = 1 };
+enum { MSC_OK = 0, MSC_ERR_BAD_ARG = -1, MSC_ERR_LAUNCH = -2, MSC_ERR_UNSUPPORTED = -3 };
+enum { MSC_ACT_NONE = 0, MSC_ACT_RELU = 1, MSC_ACT_GELU = 2, MSC_ACT_TANH = 3, MSC_ACT_SIGMOID = 4 };
+enum { MSC_CH_AWGN = 0, MSC_CH_RAYLEIGH = 1 };
+
+const char* msc_strerror(int code);
+int msc_version(void);
+/* bytes of fp32 workspace msc_conv2d_wgrad / msc_linear_wgrad need for their split-K slabs */
+int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * ImageEncoder / BEV conv stack: implicit-GEMM convolution (no im2col buffer).
+ * x:[B,H,W,Cin] w:[Cout,KH,KW,Cin] y:[B,Ho,Wo,Cout], Ho=(H+2p-KH)/s+1.  Cin must be a power of two
+ * >= 16/sizeof(T) (the RGB image is padded to 8 channels by msc_image_to_nhwc).
+ * bn_partial (may be NULL): fp32 [ceil(B*Ho*Wo/128)][2][Cout] per-row-block column sums / sums of
+ * squares of the fp32 accumulators, reduced in fixed order by msc_bn_finalize (deterministic). */
+int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_partial, int B, int H, int W,
+                   int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream);
+/* dx:[B,H,W,Cin] = conv-transpose of dy:[B,Ho,Wo,Cout] with wt:[Cin,KH,KW,Cout] (msc_permute3_cast)
+ * + res (optional T [B,H,W,Cin]: the gradient arriving over a residual/identity branch). */
+int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, void* dx, int B, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream);
+/* dw (fp32, OHWI) = sum over pixels dy^T x.  accumulate!=0 adds to dw.  ws: see msc_wgrad_workspace_bytes. */
+int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,
+                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                     int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FusionTransformer / SemanticEncoder / SemanticDecoder / heads: dense layers.
+ * y[M,N] = act(x[M,K] w[N,K]^T + bias[N]) + res[M,N];  pre (may be NULL) receives the
+ * pre-activation (needed by GELU/tanh backward).  bias,res,pre optional.  bias is fp32. */
+int msc_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, void* pre,
+                   int M, int N, int K, int act, int dtype, void* stream);
+/* dx[M,K] = dy[M,N] wt[K,N]^T  (wt = w transposed, [K][N] row-major) */
+int msc_linear_dgrad(const void* dy, const void* wt, void* dx, int M, int N, int K, int dtype, void* stream);
+/* dw[N,K] (fp32) = dy[M,N]^T x[M,K] */
+int msc_linear_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int M, int N,
+                     int K, int accumulate, int dtype, void* stream);
+
+/* General strided-batched GEMM used by the unfused attention path:
+ *   C[z][m][n] = alpha * sum_k A(z,m,k) B(z,n,k)
+ * a_kmajor/b_kmajor = 1: operand stored [row][k] (k contiguous); 0: stored [k][row] (row contiguous).
+ * Leading dimensions must be multiples of 16 bytes; a row may end inside a 16-byte chunk provided the
+ * padded tail up to ld is allocated and holds zeros (the softmax kernels write such pads).
+ * batch index z = zo*batch_inner + zi; operand offset = zo*s?_o + zi*s?_i (in elements).
+ * c_f32 != 0 writes fp32 output, else T. */
+int msc_gemm_batched(const void* A, const void* Bm, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                     int64_t ldc, int a_kmajor, int b_kmajor, int batch, int batch_inner, int64_t sa_o,
+                     int64_t sa_i, int64_t sb_o, int64_t sb_i, int64_t sc_o, int64_t sc_i, float alpha,
+                     int c_f32, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm (training-mode batch statistics, per-GPU under DP) and LayerNorm.
+ * msc_bn_finalize: mean/rstd [C] from the conv epilogue partials (fp64 combine, fixed order).
+ * msc_bn_apply   : y = relu?(gamma*(x-mean)*rstd + beta + res?)            x,y,res: T [rows][C]
+ * msc_bn_bwd     : dz = dy*(y>0 if relu); dx (T); dres = dz (optional, T); dgamma/dbeta fp32
+ *                  ws >= msc_bn_bwd_workspace_bytes(C). */
+int msc_bn_finalize(const float* partial, int nblk, int C, int64_t count, float eps, float* mean, float* rstd,
+                    void* stream);
+int msc_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 const void* res, void* y, int64_t rows, int C, int relu, int dtype, void* stream);
+int64_t msc_bn_bwd_workspace_bytes(int C);
+int msc_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
+               const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, int64_t rows,
+               int C, int relu, int accumulate, int dtype, void* stream);
+int msc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int64_t rows, int D, float eps, int dtype, void* stream);
+int64_t msc_layernorm_bwd_workspace_bytes(int64_t rows, int D);
+/* dx = LN-backward(dy) + dadd (dadd optional: gradient arriving over the residual branch) */
+int msc_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      const void* dadd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
+                      int accumulate, int dtype, void* stream);
+/* out[c] (+)= sum_r x[r][c] — bias and positional-embedding gradients.  ws >= msc_colsum_workspace_bytes(cols) */
+int64_t msc_colsum_workspace_bytes(int64_t cols);
+int msc_colsum(const void* x, float* out, float* ws, int64_t rows, int64_t cols, int accumulate, int dtype,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout, pooling, activation-backward, weight preparation, optimizer (all HBM-bound). */
+int msc_image_to_nhwc(const float* img_nchw, void* out, int B, int C, int H, int W, int Cpad, int dtype,
+                      void* stream);
+int msc_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int K, int S, int P,
+                    int dtype, void* stream);
+int msc_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int K, int S, int P,
+                    int dtype, void* stream);
+/* tokens[b] = concat(s0[b] (n0 rows), s1[b] (n1), s2[b] (n2)) + pos[T][D] */
+int msc_tokens_assemble(const void* s0, const void* s1, const void* s2, const float* pos, void* out, int B, int n0,
+                        int n1, int n2, int D, int dtype, void* stream);
+int msc_tokens_split(const void* dout, void* d0, void* d1, void* d2, int B, int n0, int n1, int n2, int D,
+                     int dtype, void* stream);
+int msc_meanpool_fwd(const void* x, void* y, int B, int T, int D, int dtype, void* stream);
+int msc_meanpool_bwd(const void* dy, void* dx, int B, int T, int D, int dtype, void* stream);
+/* ref = output for relu/tanh/sigmoid, pre-activation for gelu */
+int msc_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, int dtype, void* stream);
+int msc_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
+/* dst[k][j][i] = src[i][j][k]; OHWI -> [Cin][KH*KW][Cout] with (d0,d1,d2)=(Cout,KH*KW,Cin); linear W^T with d1=1 */
+int msc_permute3_cast(const float* src, void* dst, int d0, int d1, int d2, int dtype, void* stream);
+/* torch.optim.Adam semantics; shadow (T, may be NULL) receives the updated low-precision copy */
+int msc_adam_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SemanticEncoder power normalisation + Channel (AWGN / Rayleigh).  x,y: T [B][k]; noise/fading:
+ * fp32 [B][k] or NULL (then Philox4x32-10 with `seed`); snr_db: fp32 [B]; scale: fp32 [B] (saved). */
+int msc_channel_fwd(const void* x, const float* noise, const float* fading, const float* snr_db, void* y,
+                    float* scale, int B, int k, int mode, uint64_t seed, int dtype, void* stream);
+int msc_channel_bwd(const void* dy, const void* x, const float* scale, void* dx, int B, int k, int dtype,
+                    void* stream);
+int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LiDAR / BEV encoder front end: point MLP (4->64, ReLU) + scatter-max into [B][G][G][64]. */
+int msc_pillar_fwd(const float* points, const float* w, const float* bias, float* grid_f32, void* grid_out, int B,
+                   int Np, int G, int C, float range_lo, float cell, int dtype, void* stream);
+int64_t msc_pillar_bwd_workspace_bytes(void);
+int msc_pillar_bwd(const float* points, const float* w, const float* bias, const float* grid_f32,
+                   const void* dgrid, float* dw, float* db, float* ws, int B, int Np, int G, int C, float range_lo,
+                   float cell, int accumulate, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Policy / value head, losses, attention softmax. */
+int msc_argmax_rows(const void* x, int64_t* out, int64_t rows, int n, int64_t ld, int dtype, void* stream);
+/* head: T [B][ld], cols 0..A-1 logits, col A value.  terms fp32[4] = total, policy, value, entropy. */
+int msc_ppo_loss(const void* head, const int64_t* actions, const float* old_logp, const float* adv,
+                 const float* ret, float* terms, void* dhead, int B, int A, int ld, float clip_eps, float c_v,
+                 float c_e, int dtype, void* stream);
+int64_t msc_recon_loss_workspace_bytes(int B);
+/* recon: T [B][G*G][P*P*3]; img fp32 NCHW; sse fp32 [B]; drecon = gscale*(recon-img) (may be NULL) */
+int msc_recon_loss(const void* recon, const float* img_nchw, float* sse, void* drecon, float* ws, int B, int G,
+                   int P, float gscale, int dtype, void* stream);
+int msc_unpatchify(const void* recon, float* img_nchw, int B, int G, int P, int dtype, void* stream);
+int msc_softmax_fwd(const float* S, void* P, int64_t rows, int n, int ld, int dtype, void* stream);
+int msc_softmax_bwd(const float* dP, const void* P, void* dS, int64_t rows, int n, int ld, int dtype,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSC_H_ */

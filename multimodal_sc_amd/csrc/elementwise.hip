@@ -1,0 +1,344 @@
+// elementwise.hip — HBM-bound layout / pooling / activation / optimizer kernels of the path.
+// 16-byte vector accesses, grid-stride loops capped at ~16 blocks per CU, no atomics.
+// Build-authored (the upstream reference has no code, SURVEY.md finding zero).
+#include "msc_common.h"
+
+static inline int ew_blocks(long n, int bs = 256) {
+  long b = (n + bs - 1) / bs;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// ---------------------------------------------------------------- image NCHW fp32 -> NHWC(Cpad) T
+template <typename T>
+__global__ void image_to_nhwc_kernel(const float* __restrict__ img, T* __restrict__ out, long npix_total, int C, long HW, int Cpad) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix_total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, pix = i % HW;
+    for (int c = 0; c < Cpad; ++c) {
+      const float v = c < C ? img[(b * C + c) * HW + pix] : 0.f;
+      msc_traits<T>::st(out + i * Cpad + c, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- max-pool (NHWC), argmax kept as uint8 tap id
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int B, int H, int W,
+                                   int C, int Ho, int Wo, int K, int S, int P) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int cv = C / VEC;
+  const long n = (long)B * Ho * Wo * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * VEC;
+    long t = i / cv;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float best[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int kh = 0; kh < K; ++kh) {
+      const int hi = ho * S - P + kh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int wi = wo * S - P + kw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        vecf<T> v;
+        v.load(x + (((long)b * H + hi) * W + wi) * C + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (v.v[j] > best[j]) { best[j] = v.v[j]; bi[j] = kh * K + kw; }
+      }
+    }
+    vecf<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
+    const long oo = (((long)b * Ho + ho) * Wo + wo) * C + c0;
+    o.store(y + oo);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) idx[oo + j] = (uint8_t)bi[j];
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int B, int H,
+                                   int W, int C, int Ho, int Wo, int K, int S, int P) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int cv = C / VEC;
+  const long n = (long)B * H * W * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * VEC;
+    long t = i / cv;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    vecf<T> acc;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
+    for (int kh = 0; kh < K; ++kh) {
+      const int th = h + P - kh;
+      if (th < 0 || th % S) continue;
+      const int ho = th / S;
+      if (ho >= Ho) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int tw = w + P - kw;
+        if (tw < 0 || tw % S) continue;
+        const int wo = tw / S;
+        if (wo >= Wo) continue;
+        const long oo = (((long)b * Ho + ho) * Wo + wo) * C + c0;
+        vecf<T> g;
+        g.load(dy + oo);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (idx[oo + j] == kh * K + kw) acc.v[j] += g.v[j];
+      }
+    }
+    acc.store(dx + (((long)b * H + h) * W + w) * C + c0);
+  }
+}
+
+// ---------------------------------------------------------------- token assembly: concat(modalities) + positional embedding
+template <typename T>
+__global__ void tokens_assemble_kernel(const T* __restrict__ s0, const T* __restrict__ s1, const T* __restrict__ s2,
+                                       const float* __restrict__ pos, T* __restrict__ out, int B, int n0, int n1, int n2, int D) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int Tt = n0 + n1 + n2, dv = D / VEC;
+  const long n = (long)B * Tt * dv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int d0 = (int)(i % dv) * VEC;
+    const long r = i / dv;
+    const int t = (int)(r % Tt);
+    const long b = r / Tt;
+    const T* src;
+    if (t < n0) src = s0 + ((b * n0 + t) * D + d0);
+    else if (t < n0 + n1) src = s1 + ((b * n1 + (t - n0)) * D + d0);
+    else src = s2 + ((b * n2 + (t - n0 - n1)) * D + d0);
+    vecf<T> v;
+    v.load(src);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v.v[j] += pos[(long)t * D + d0 + j];
+    v.store(out + r * D + d0);
+  }
+}
+// backward: scatter the rows of dout back to the three modality gradients (pure copy)
+template <typename T>
+__global__ void tokens_split_kernel(const T* __restrict__ dout, T* __restrict__ d0p, T* __restrict__ d1p, T* __restrict__ d2p,
+                                    int B, int n0, int n1, int n2, int D) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int Tt = n0 + n1 + n2, dv = D / VEC;
+  const long n = (long)B * Tt * dv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int d0 = (int)(i % dv) * VEC;
+    const long r = i / dv;
+    const int t = (int)(r % Tt);
+    const long b = r / Tt;
+    T* dst;
+    if (t < n0) dst = d0p ? d0p + ((b * n0 + t) * D + d0) : nullptr;
+    else if (t < n0 + n1) dst = d1p ? d1p + ((b * n1 + (t - n0)) * D + d0) : nullptr;
+    else dst = d2p ? d2p + ((b * n2 + (t - n0 - n1)) * D + d0) : nullptr;
+    if (dst) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(dout + r * D + d0);
+  }
+}
+
+// ---------------------------------------------------------------- mean over tokens
+template <typename T>
+__global__ void meanpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Tt, int D) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int dv = D / VEC;
+  const long n = (long)B * dv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int d0 = (int)(i % dv) * VEC;
+    const long b = i / dv;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    for (int t = 0; t < Tt; ++t) {
+      vecf<T> v;
+      v.load(x + ((b * Tt + t) * D + d0));
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += v.v[j];
+    }
+    vecf<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = s[j] / (float)Tt;
+    o.store(y + b * D + d0);
+  }
+}
+template <typename T>
+__global__ void meanpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Tt, int D) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int dv = D / VEC;
+  const long n = (long)B * Tt * dv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int d0 = (int)(i % dv) * VEC;
+    const long r = i / dv;
+    const long b = r / Tt;
+    vecf<T> v;
+    v.load(dy + b * D + d0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v.v[j] /= (float)Tt;
+    v.store(dx + r * D + d0);
+  }
+}
+
+// ---------------------------------------------------------------- activation backward
+// ref = output y for relu/tanh/sigmoid, pre-activation for gelu
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ ref, T* __restrict__ dx, long nvec, int act) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    vecf<T> g, r;
+    g.load(dy + i * VEC);
+    r.load(ref + i * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float y = r.v[j];
+      float d;
+      switch (act) {
+        case MSC_ACT_RELU: d = y > 0.f ? 1.f : 0.f; break;
+        case MSC_ACT_TANH: d = 1.f - y * y; break;
+        case MSC_ACT_SIGMOID: d = y * (1.f - y); break;
+        case MSC_ACT_GELU: d = 0.5f * (1.f + erff(y * 0.70710678118654752f)) + y * 0.3989422804014327f * __expf(-0.5f * y * y); break;
+        default: d = 1.f;
+      }
+      g.v[j] *= d;
+    }
+    g.store(dx + i * VEC);
+  }
+}
+
+// ---------------------------------------------------------------- fp32 -> T casts / permutes of weights
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    msc_traits<T>::st(dst + i, src[i]);
+}
+// dst[k][j][i] = src[i][j][k]  (src dims d0,d1,d2).  32x32 LDS tile transposes over (i,k) for each j.
+template <typename T>
+__global__ void permute3_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int d2) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.z;
+  const int i0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, k = k0 + tx;
+    tile[r][tx] = (i < d0 && k < d2) ? src[((long)i * d1 + j) * d2 + k] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, i = i0 + tx;
+    if (k < d2 && i < d0) msc_traits<T>::st(dst + ((long)k * d1 + j) * d0 + i, tile[tx][r]);
+  }
+}
+
+// ---------------------------------------------------------------- fused Adam (+ low-precision shadow copy)
+template <typename T>
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            T* __restrict__ shadow, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                            float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pi;
+    if (shadow) msc_traits<T>::st(shadow + i, pi);
+  }
+}
+
+// ================================================================ C-ABI
+#define DISPATCH_T(dtype, CALL)              \
+  if (dtype == MSC_F32) { typedef float T; CALL; }        \
+  else if (dtype == MSC_BF16) { typedef bf16_t T; CALL; } \
+  else return MSC_ERR_BAD_ARG;
+
+extern "C" int msc_image_to_nhwc(const float* img_nchw, void* out, int B, int C, int H, int W, int Cpad, int dtype, void* stream) {
+  MSC_CHECK_ARG(img_nchw && out && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C);
+  const long npix = (long)B * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(ew_blocks(npix)), dim3(256), 0, (hipStream_t)stream,
+                                       img_nchw, (T*)out, npix, C, (long)H * W, Cpad));
+  return msc_launch_status();
+}
+
+extern "C" int msc_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int K, int S, int P, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && y && idx && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && K * K <= 255 && S > 0 && P >= 0 && P < K);
+  MSC_CHECK_ARG(C % (dtype == MSC_F32 ? 4 : 8) == 0);
+  const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_blocks((long)B * Ho * Wo * C / msc_traits<T>::VEC)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)x, (T*)y, idx, B, H, W, C, Ho, Wo, K, S, P));
+  return msc_launch_status();
+}
+
+extern "C" int msc_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int K, int S, int P, int dtype, void* stream) {
+  MSC_CHECK_ARG(dy && dx && idx && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && S > 0 && P >= 0 && P < K);
+  MSC_CHECK_ARG(C % (dtype == MSC_F32 ? 4 : 8) == 0);
+  const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_blocks((long)B * H * W * C / msc_traits<T>::VEC)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, H, W, C, Ho, Wo, K, S, P));
+  return msc_launch_status();
+}
+
+extern "C" int msc_tokens_assemble(const void* s0, const void* s1, const void* s2, const float* pos, void* out, int B, int n0, int n1,
+                                   int n2, int D, int dtype, void* stream) {
+  MSC_CHECK_ARG(pos && out && B > 0 && n0 >= 0 && n1 >= 0 && n2 >= 0 && n0 + n1 + n2 > 0 && D > 0);
+  MSC_CHECK_ARG((n0 == 0 || s0) && (n1 == 0 || s1) && (n2 == 0 || s2));
+  MSC_CHECK_ARG(D % (dtype == MSC_F32 ? 4 : 8) == 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(tokens_assemble_kernel<T>, dim3(ew_blocks((long)B * (n0 + n1 + n2) * D / msc_traits<T>::VEC)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)s0, (const T*)s1, (const T*)s2, pos, (T*)out, B, n0, n1, n2, D));
+  return msc_launch_status();
+}
+
+extern "C" int msc_tokens_split(const void* dout, void* d0, void* d1, void* d2, int B, int n0, int n1, int n2, int D, int dtype, void* stream) {
+  MSC_CHECK_ARG(dout && B > 0 && n0 >= 0 && n1 >= 0 && n2 >= 0 && n0 + n1 + n2 > 0 && D > 0);
+  MSC_CHECK_ARG(D % (dtype == MSC_F32 ? 4 : 8) == 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(tokens_split_kernel<T>, dim3(ew_blocks((long)B * (n0 + n1 + n2) * D / msc_traits<T>::VEC)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)dout, (T*)d0, (T*)d1, (T*)d2, B, n0, n1, n2, D));
+  return msc_launch_status();
+}
+
+extern "C" int msc_meanpool_fwd(const void* x, void* y, int B, int Tt, int D, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && y && B > 0 && Tt > 0 && D > 0 && D % (dtype == MSC_F32 ? 4 : 8) == 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(meanpool_fwd_kernel<T>, dim3(ew_blocks((long)B * D / msc_traits<T>::VEC, 64)), dim3(64), 0, (hipStream_t)stream,
+                                       (const T*)x, (T*)y, B, Tt, D));
+  return msc_launch_status();
+}
+extern "C" int msc_meanpool_bwd(const void* dy, void* dx, int B, int Tt, int D, int dtype, void* stream) {
+  MSC_CHECK_ARG(dy && dx && B > 0 && Tt > 0 && D > 0 && D % (dtype == MSC_F32 ? 4 : 8) == 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(meanpool_bwd_kernel<T>, dim3(ew_blocks((long)B * Tt * D / msc_traits<T>::VEC)), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)dy, (T*)dx, B, Tt, D));
+  return msc_launch_status();
+}
+
+extern "C" int msc_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, int dtype, void* stream) {
+  MSC_CHECK_ARG(dy && ref && dx && n > 0 && n % (dtype == MSC_F32 ? 4 : 8) == 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_blocks(n / msc_traits<T>::VEC)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                                       (const T*)ref, (T*)dx, (long)(n / msc_traits<T>::VEC), act));
+  return msc_launch_status();
+}
+
+extern "C" int msc_cast(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+  MSC_CHECK_ARG(src && dst && n > 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, (long)n));
+  return msc_launch_status();
+}
+
+extern "C" int msc_permute3_cast(const float* src, void* dst, int d0, int d1, int d2, int dtype, void* stream) {
+  MSC_CHECK_ARG(src && dst && d0 > 0 && d1 > 0 && d2 > 0 && d1 <= 65535);
+  dim3 grid((unsigned)cdiv(d2, 32), (unsigned)cdiv(d0, 32), (unsigned)d1);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(permute3_cast_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst, d0, d1, d2));
+  return msc_launch_status();
+}
+
+extern "C" int msc_adam_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, int dtype, void* stream) {
+  MSC_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                                       (T*)(dtype == MSC_F32 ? nullptr : shadow), (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale));
+  return msc_launch_status();
+}

@@ -1,0 +1,546 @@
+// gemm.hip — the one MFMA contraction kernel of the path, specialised by operand access mode:
+//   C[z][m][n] = epilogue( sum_k A(m,k) * B(n,k) )
+// Operand modes (template parameters, one per operand):
+//   OPM_DENSE_K     operand stored [row][k], k contiguous                    (linear fwd, QK^T ...)
+//   OPM_DENSE_MN    operand stored [k][row], row contiguous (transposed into LDS on the write)
+//   OPM_CONV_FWD    A = NHWC activations gathered on the fly, rows=(b,ho,wo), k=(kh,kw,cin)
+//   OPM_CONV_DGRAD  A = NHWC output-gradients gathered, rows=(b,h,w), k=(kh,kw,cout)
+//   OPM_CONV_WGRAD  B = NHWC activations gathered, reduction k=(b,ho,wo), rows n=(kh,kw,cin)
+// so convolution is an implicit GEMM: there is no im2col buffer in HBM.
+//
+// Tile: 128 x BN (BN = 128 or 64) x 64 bytes of K per step; 256 threads = 4 waves in 2x2, each wave
+// owns (64 x BN/2) as 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, or the exact-fp32
+// v_mfma_f32_32x32x2_f32 in parity mode).  Global->register->LDS staging, two LDS buffers, the
+// global loads of tile t+1 are issued before the MFMAs of tile t and written after them (one barrier
+// per K step).  LDS rows are 64 B; 16-byte chunk c of row r lives at c ^ ((r>>2)&3), which makes the
+// ds_read_b128 fragment reads conflict-free (MI355X_MICROARCH.md §LDS, 16-lane groups).
+//
+// Build-authored: the upstream reference has no code (SURVEY.md finding zero); roles per
+// BASELINE.json: ImageEncoder/BEV conv stack, FusionTransformer, SemanticEncoder/Decoder, heads.
+#include "msc_common.h"
+
+enum { OPM_DENSE_K = 0, OPM_DENSE_MN = 1, OPM_CONV_FWD = 2, OPM_CONV_DGRAD = 3, OPM_CONV_WGRAD = 4 };
+
+struct GemmParams {
+  const void* A; const void* B; void* C; void* C2; const void* res; const float* bias; float* stats;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int batch_inner; long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
+  int nsplit, tiles_per_split;
+  float alpha; int act; int out_f32;
+  // geometry of the gathered NHWC tensor (conv modes)
+  int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
+
+template <int MODE> struct mode_is_kmajor { static constexpr bool value = (MODE == OPM_DENSE_K || MODE == OPM_CONV_FWD || MODE == OPM_CONV_DGRAD); };
+
+__device__ __forceinline__ int lds_chunk_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+// ------------------------------------------------------------------------------------------------
+// Operand loader: global -> registers (16-byte chunks) -> LDS tile [ROWS][64 B] (k contiguous).
+template <typename T, int MODE, int ROWS> struct OperandLoader {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int KT = 64 / sizeof(T);
+  static constexpr int NCH = ROWS * 4 / 256;   // chunks per thread per K step
+  static constexpr int CPR = ROWS / VEC;        // chunks per reduction row (MN-major modes)
+
+  const T* ptr[NCH];   // dense modes: running pointer
+  int kk[NCH];         // current k (reduction index) of the chunk
+  bool ok[NCH];        // row (k-major) or column (mn-major) inside the matrix
+  // conv state
+  int a0[NCH], a1[NCH], a2[NCH];  // fwd/dgrad: hi0, wi0, kh ; wgrad: ho, wo, b
+  int a3[NCH], a4[NCH];           // fwd/dgrad: kw, cin     ; wgrad: kh, kw
+  long boff[NCH];                 // batch base offset (fwd/dgrad) or cin (wgrad)
+
+  __device__ __forceinline__ void init(const GemmParams& p, const T* base, long ld, int rows_total,
+                                       int row0, int k0) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      if constexpr (MODE == OPM_DENSE_K) {
+        const int row = row0 + (id >> 2), c = id & 3;
+        ok[i] = row < rows_total;
+        kk[i] = k0 + c * VEC;
+        ptr[i] = base + (long)(ok[i] ? row : 0) * ld + kk[i];
+      } else if constexpr (MODE == OPM_DENSE_MN) {
+        const int r = id / CPR, cc = id % CPR;
+        const int col = row0 + cc * VEC;
+        ok[i] = col < rows_total;
+        kk[i] = k0 + r;
+        ptr[i] = base + (long)kk[i] * ld + (ok[i] ? col : 0);
+      } else if constexpr (MODE == OPM_CONV_FWD) {
+        const int row = row0 + (id >> 2), c = id & 3;
+        ok[i] = row < rows_total;
+        const int rr = ok[i] ? row : 0;
+        const int wo = rr % p.cWo, t = rr / p.cWo;
+        const int ho = t % p.cHo, b = t / p.cHo;
+        a0[i] = ho * p.cS - p.cP;
+        a1[i] = wo * p.cS - p.cP;
+        boff[i] = (long)b * p.cH * p.cW * p.cC;
+        const int k = k0 + c * VEC;
+        const int tap = k >> p.cLogC;
+        a4[i] = k & (p.cC - 1);
+        a2[i] = tap / p.cKW;
+        a3[i] = tap - a2[i] * p.cKW;
+      } else if constexpr (MODE == OPM_CONV_DGRAD) {
+        // rows are INPUT pixels (b,h,w) of size cH x cW; gathered tensor is dy [cB,cHo,cWo,cC]
+        const int row = row0 + (id >> 2), c = id & 3;
+        ok[i] = row < rows_total;
+        const int rr = ok[i] ? row : 0;
+        const int w = rr % p.cW, t = rr / p.cW;
+        const int h = t % p.cH, b = t / p.cH;
+        a0[i] = h + p.cP;
+        a1[i] = w + p.cP;
+        boff[i] = (long)b * p.cHo * p.cWo * p.cC;
+        const int k = k0 + c * VEC;
+        const int tap = k >> p.cLogC;
+        a4[i] = k & (p.cC - 1);
+        a2[i] = tap / p.cKW;
+        a3[i] = tap - a2[i] * p.cKW;
+      } else {  // OPM_CONV_WGRAD: columns n=(kh,kw,cin) fixed per thread, reduction over (b,ho,wo)
+        const int r = id / CPR, cc = id % CPR;
+        const int col = row0 + cc * VEC;
+        ok[i] = col < rows_total;
+        const int cl = ok[i] ? col : 0;
+        const int tap = cl >> p.cLogC;
+        boff[i] = cl & (p.cC - 1);
+        a3[i] = tap / p.cKW;
+        a4[i] = tap - a3[i] * p.cKW;
+        const int pix = k0 + r;
+        kk[i] = pix;
+        a1[i] = pix % p.cWo;
+        const int t = pix / p.cWo;
+        a0[i] = t % p.cHo;
+        a2[i] = t / p.cHo;
+      }
+    }
+  }
+
+  // load the current K step into regs (zeros where out of range) and advance by one K step
+  __device__ __forceinline__ void load(const GemmParams& p, const T* base, long ld, int klimit, uint4 (&regs)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if constexpr (MODE == OPM_DENSE_K) {
+        if (ok[i] && kk[i] < klimit) v = *reinterpret_cast<const uint4*>(ptr[i]);
+        ptr[i] += KT;
+        kk[i] += KT;
+      } else if constexpr (MODE == OPM_DENSE_MN) {
+        if (ok[i] && kk[i] < klimit) v = *reinterpret_cast<const uint4*>(ptr[i]);
+        ptr[i] += (long)KT * ld;
+        kk[i] += KT;
+      } else if constexpr (MODE == OPM_CONV_FWD) {
+        const int hi = a0[i] + a2[i], wi = a1[i] + a3[i];
+        if (ok[i] && a2[i] < p.cKH && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
+          v = *reinterpret_cast<const uint4*>(base + boff[i] + ((long)(hi * p.cW + wi) << p.cLogC) + a4[i]);
+        int cin = a4[i] + KT;
+        a3[i] += cin >> p.cLogC;
+        a4[i] = cin & (p.cC - 1);
+        while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
+      } else if constexpr (MODE == OPM_CONV_DGRAD) {
+        const int th = a0[i] - a2[i], tw = a1[i] - a3[i];
+        const int sm = p.cS - 1;
+        const int ho = th >> p.cLogS, wo = tw >> p.cLogS;
+        if (ok[i] && a2[i] < p.cKH && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && ho < p.cHo && wo < p.cWo)
+          v = *reinterpret_cast<const uint4*>(base + boff[i] + ((long)(ho * p.cWo + wo) << p.cLogC) + a4[i]);
+        int co = a4[i] + KT;
+        a3[i] += co >> p.cLogC;
+        a4[i] = co & (p.cC - 1);
+        while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
+      } else {
+        const int hi = a0[i] * p.cS - p.cP + a3[i], wi = a1[i] * p.cS - p.cP + a4[i];
+        if (ok[i] && kk[i] < klimit && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
+          v = *reinterpret_cast<const uint4*>(base + ((((long)a2[i] * p.cH + hi) * p.cW + wi) << p.cLogC) + boff[i]);
+        kk[i] += KT;
+        a1[i] += KT;
+        while (a1[i] >= p.cWo) {
+          a1[i] -= p.cWo;
+          if (++a0[i] == p.cHo) { a0[i] = 0; ++a2[i]; }
+        }
+      }
+      regs[i] = v;
+    }
+  }
+
+  __device__ __forceinline__ void store(char* tile, const uint4 (&regs)[NCH]) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      if constexpr (mode_is_kmajor<MODE>::value) {
+        *reinterpret_cast<uint4*>(tile + lds_chunk_off(id >> 2, id & 3)) = regs[i];
+      } else {
+        // transpose on the write: element j of the chunk is (row cc*VEC+j, k = r)
+        const int r = id / CPR, cc = id % CPR;
+        const int kb = r * (int)sizeof(T);
+        const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const int row = cc * VEC + j;
+          char* dst = tile + lds_chunk_off(row, kb >> 4) + (kb & 15);
+          if constexpr (sizeof(T) == 2)
+            *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
+          else
+            *reinterpret_cast<uint32_t*>(dst) = w[j];
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int AMODE, int BMODE, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+  constexpr int BM = 128;
+  constexpr int KT = 64 / sizeof(T);
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x % ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int zz = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
+  const int zo = zz / p.batch_inner, zi = zz % p.batch_inner;
+
+  const T* Ab = reinterpret_cast<const T*>(p.A) + zo * p.sa_o + zi * p.sa_i;
+  const T* Bb = reinterpret_cast<const T*>(p.B) + zo * p.sb_o + zi * p.sb_i;
+
+  const int nk_total = (p.K + KT - 1) / KT;
+  const int kt_begin = split * p.tiles_per_split;
+  const int kt_end = min(nk_total, kt_begin + p.tiles_per_split);
+
+  OperandLoader<T, AMODE, BM> la;
+  OperandLoader<T, BMODE, BN> lb;
+  la.init(p, Ab, p.lda, p.M, m0, kt_begin * KT);
+  lb.init(p, Bb, p.ldb, p.N, n0, kt_begin * KT);
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[OperandLoader<T, AMODE, BM>::NCH], rb[OperandLoader<T, BMODE, BN>::NCH];
+
+  if (kt_begin < kt_end) {
+    la.load(p, Ab, p.lda, p.K, ra);
+    lb.load(p, Bb, p.ldb, p.K, rb);
+    la.store(smem, ra);
+    lb.store(smem + A_BYTES, rb);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = (kt + 1 < kt_end);
+    if (more) {
+      la.load(p, Ab, p.lda, p.K, ra);
+      lb.load(p, Bb, p.ldb, p.K, rb);
+    }
+    const char* As = smem + cur * (A_BYTES + B_BYTES);
+    const char* Bs = As + A_BYTES;
+    const int lr = lane & 31, lh = lane >> 5;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        mfma_bf16x8_t fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          fa[i] = *reinterpret_cast<const mfma_bf16x8_t*>(As + lds_chunk_off(wm * WM + i * 32 + lr, 2 * ks + lh));
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          fb[j] = *reinterpret_cast<const mfma_bf16x8_t*>(Bs + lds_chunk_off(wn * WN + j * 32 + lr, 2 * ks + lh));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int k = 2 * ks + lh;  // float index inside the 16-float row
+        float fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          fa[i] = *reinterpret_cast<const float*>(As + lds_chunk_off(wm * WM + i * 32 + lr, k >> 2) + (k & 3) * 4);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          fb[j] = *reinterpret_cast<const float*>(Bs + lds_chunk_off(wn * WN + j * 32 + lr, k >> 2) + (k & 3) * 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) {
+      char* An = smem + (cur ^ 1) * (A_BYTES + B_BYTES);
+      la.store(An, ra);
+      lb.store(An + A_BYTES, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const int lr = lane & 31, lh = lane >> 5;
+  if (p.nsplit > 1 || p.out_f32) {
+    float* Cf = reinterpret_cast<float*>(p.C) + (p.nsplit > 1 ? (long)split * p.M * p.ldc : (zo * p.sc_o + zi * p.sc_i));
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M && n < p.N) Cf[(long)m * p.ldc + n] = p.alpha * acc[i][j][r];
+        }
+      }
+    return;
+  }
+
+  T* Cb = reinterpret_cast<T*>(p.C) + zo * p.sc_o + zi * p.sc_i;
+  T* C2 = reinterpret_cast<T*>(p.C2);
+  const T* Rs = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * WN + j * 32 + lr;
+    const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = p.alpha * acc[i][j][r] + bv;
+        s1 += v;
+        s2 += v * v;
+        if (m < p.M && n < p.N) {
+          const long o = (long)m * p.ldc + n;
+          if (C2) msc_traits<T>::st(C2 + o, v);
+          v = act_apply(v, p.act);
+          if (Rs) v += msc_traits<T>::ld(Rs + o);
+          msc_traits<T>::st(Cb + o, v);
+        }
+      }
+    }
+    if (p.stats) {
+      // rows beyond M were loaded as zeros and conv has no bias, so they add nothing to the sums
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      float* red = reinterpret_cast<float*>(smem);  // [2 wm][2 stat][BN]
+      __syncthreads();
+      if (lh == 0) {
+        red[(wm * 2 + 0) * BN + wn * WN + j * 32 + lr] = s1;
+        red[(wm * 2 + 1) * BN + wn * WN + j * 32 + lr] = s2;
+      }
+      __syncthreads();
+      if (wm == 0 && lh == 0 && n < p.N) {
+        const int c = wn * WN + j * 32 + lr;
+        float* st = p.stats + (long)tile_m * 2 * p.N;
+        st[n] = red[(0 * 2 + 0) * BN + c] + red[(1 * 2 + 0) * BN + c];
+        st[p.N + n] = red[(0 * 2 + 1) * BN + c] + red[(1 * 2 + 1) * BN + c];
+      }
+    }
+  }
+}
+
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i]   (fixed order: bitwise reproducible)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n, int nsplit, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(long)k * n + i];
+    out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int AMODE, int BMODE>
+static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
+  const bool narrow = p.N <= 64;
+  const int BN = narrow ? 64 : 128;
+  dim3 grid((unsigned)(cdiv(p.M, 128) * cdiv(p.N, BN)), 1, (unsigned)(batch * p.nsplit));
+  if (narrow)
+    hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128>), grid, dim3(256), 0, st, p);
+  return msc_launch_status();
+}
+
+template <int AMODE, int BMODE>
+static int launch_gemm_dt(const GemmParams& p, int batch, int dtype, hipStream_t st) {
+  if (dtype == MSC_F32) return launch_gemm<float, AMODE, BMODE>(p, batch, st);
+  if (dtype == MSC_BF16) return launch_gemm<bf16_t, AMODE, BMODE>(p, batch, st);
+  return MSC_ERR_BAD_ARG;
+}
+
+static GemmParams base_params() {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.batch_inner = 1;
+  p.nsplit = 1;
+  p.tiles_per_split = 1 << 30;
+  p.alpha = 1.f;
+  return p;
+}
+
+static inline int vec_of(int dtype) { return dtype == MSC_F32 ? 4 : 8; }
+static inline int kt_of(int dtype) { return dtype == MSC_F32 ? 16 : 32; }
+
+// split-K plan shared by the workspace query and the launchers (independent of dtype)
+static int plan_split(long rows_out, long cols_out, long reduce_len) {
+  const long tiles = (long)cdiv(rows_out, 128) * cdiv(cols_out, cols_out <= 64 ? 64 : 128);
+  long want = 1024 / (tiles > 0 ? tiles : 1);
+  long cap = reduce_len / 512;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  if (want > 512) want = 512;
+  return (int)want;
+}
+
+extern "C" int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len) {
+  return (int64_t)plan_split(rows_out, cols_out, reduce_len) * rows_out * cols_out * 4;
+}
+
+static int finish_wgrad(GemmParams& p, float* dw, float* ws, int64_t ws_bytes, long reduce_len, int accumulate,
+                        int dtype, hipStream_t st, int (*launch)(const GemmParams&, int, int, hipStream_t)) {
+  const int KT = kt_of(dtype);
+  const int nk = cdiv(reduce_len, KT);
+  int ns = plan_split(p.M, p.N, reduce_len);
+  int tps = cdiv(nk, ns);
+  ns = cdiv(nk, tps);
+  if ((int64_t)ns * p.M * p.N * 4 > ws_bytes || !ws) return MSC_ERR_BAD_ARG;
+  p.nsplit = ns;
+  p.tiles_per_split = tps;
+  p.C = ws;
+  p.ldc = p.N;
+  p.out_f32 = 1;
+  // nsplit == 1 still goes through the slab so that `accumulate` has one implementation
+  if (ns == 1) { p.sc_o = 0; p.sc_i = 0; }
+  int rc = launch(p, 1, dtype, st);
+  if (rc != MSC_OK) return rc;
+  const long n = (long)p.M * p.N;
+  int blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, n, ns, accumulate);
+  return msc_launch_status();
+}
+
+static int set_conv_geom(GemmParams& p, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int s, int pad) {
+  p.cB = B; p.cH = H; p.cW = W; p.cC = C; p.cHo = Ho; p.cWo = Wo; p.cKH = KH; p.cKW = KW; p.cS = s; p.cP = pad;
+  p.cLogC = ilog2_exact(C);
+  p.cLogS = ilog2_exact(s);
+  return (p.cLogC >= 0 && p.cLogS >= 0) ? MSC_OK : MSC_ERR_BAD_ARG;
+}
+
+extern "C" int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_partial, int B, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  MSC_CHECK_ARG(Cin >= vec_of(dtype) && ilog2_exact(Cin) >= 0 && Cout > 0);
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  MSC_CHECK_ARG(Ho > 0 && Wo > 0);
+  GemmParams p = base_params();
+  p.A = x; p.B = w; p.C = y; p.stats = bn_partial;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin;
+  p.ldb = p.K; p.ldc = Cout;
+  if (set_conv_geom(p, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad) != MSC_OK) return MSC_ERR_BAD_ARG;
+  return launch_gemm_dt<OPM_CONV_FWD, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
+}
+
+extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, void* dx, int B, int H, int W, int Cin,
+                                int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+  MSC_CHECK_ARG(dy && wt && dx && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  MSC_CHECK_ARG(Cout >= vec_of(dtype) && ilog2_exact(Cout) >= 0 && Cin > 0 && ilog2_exact(stride) >= 0);
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  MSC_CHECK_ARG(Ho > 0 && Wo > 0);
+  GemmParams p = base_params();
+  p.A = dy; p.B = wt; p.C = dx; p.res = res;
+  p.M = B * H * W; p.N = Cin; p.K = KH * KW * Cout;
+  p.ldb = p.K; p.ldc = Cin;
+  if (set_conv_geom(p, B, H, W, Cout, Ho, Wo, KH, KW, stride, pad) != MSC_OK) return MSC_ERR_BAD_ARG;
+  return launch_gemm_dt<OPM_CONV_DGRAD, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
+}
+
+extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,
+                                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                                int dtype, void* stream) {
+  MSC_CHECK_ARG(x && dy && dw && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  MSC_CHECK_ARG(Cin >= vec_of(dtype) && ilog2_exact(Cin) >= 0 && Cout % vec_of(dtype) == 0);
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  MSC_CHECK_ARG(Ho > 0 && Wo > 0);
+  GemmParams p = base_params();
+  p.A = dy; p.B = x;
+  p.M = Cout; p.N = KH * KW * Cin; p.K = B * Ho * Wo;
+  p.lda = Cout;
+  if (set_conv_geom(p, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad) != MSC_OK) return MSC_ERR_BAD_ARG;
+  return finish_wgrad(p, dw, ws, ws_bytes, p.K, accumulate, dtype, (hipStream_t)stream,
+                      launch_gemm_dt<OPM_DENSE_MN, OPM_CONV_WGRAD>);
+}
+
+extern "C" int msc_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, void* pre,
+                              int M, int N, int K, int act, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  MSC_CHECK_ARG(K % vec_of(dtype) == 0);
+  GemmParams p = base_params();
+  p.A = x; p.B = w; p.C = y; p.C2 = pre; p.res = res; p.bias = bias; p.act = act;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
+  return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
+}
+
+extern "C" int msc_linear_dgrad(const void* dy, const void* wt, void* dx, int M, int N, int K, int dtype, void* stream) {
+  MSC_CHECK_ARG(dy && wt && dx && M > 0 && N > 0 && K > 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  MSC_CHECK_ARG(N % vec_of(dtype) == 0);
+  GemmParams p = base_params();
+  p.A = dy; p.B = wt; p.C = dx;
+  p.M = M; p.N = K; p.K = N; p.lda = N; p.ldb = N; p.ldc = K;
+  return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
+}
+
+extern "C" int msc_linear_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int M, int N,
+                                int K, int accumulate, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && dy && dw && M > 0 && N > 0 && K > 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  MSC_CHECK_ARG(N % vec_of(dtype) == 0 && K % vec_of(dtype) == 0);
+  GemmParams p = base_params();
+  p.A = dy; p.B = x;
+  p.M = N; p.N = K; p.K = M; p.lda = N; p.ldb = K;
+  return finish_wgrad(p, dw, ws, ws_bytes, M, accumulate, dtype, (hipStream_t)stream,
+                      launch_gemm_dt<OPM_DENSE_MN, OPM_DENSE_MN>);
+}
+
+extern "C" int msc_gemm_batched(const void* A, const void* Bm, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                                int64_t ldc, int a_kmajor, int b_kmajor, int batch, int batch_inner, int64_t sa_o,
+                                int64_t sa_i, int64_t sb_o, int64_t sb_i, int64_t sc_o, int64_t sc_i, float alpha,
+                                int c_f32, int dtype, void* stream) {
+  MSC_CHECK_ARG(A && Bm && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch_inner > 0 && batch % batch_inner == 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  const int V = vec_of(dtype);
+  MSC_CHECK_ARG(lda % V == 0 && ldb % V == 0 && sa_o % V == 0 && sa_i % V == 0 && sb_o % V == 0 && sb_i % V == 0);
+  // rows may end inside a 16-byte chunk as long as the padded tail (up to ld) is readable and finite/zero
+  GemmParams p = base_params();
+  p.A = A; p.B = Bm; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.batch_inner = batch_inner;
+  p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i;
+  p.alpha = alpha; p.out_f32 = c_f32;
+  hipStream_t st = (hipStream_t)stream;
+  if (a_kmajor && b_kmajor) return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, batch, dtype, st);
+  if (a_kmajor && !b_kmajor) return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_MN>(p, batch, dtype, st);
+  if (!a_kmajor && b_kmajor) return launch_gemm_dt<OPM_DENSE_MN, OPM_DENSE_K>(p, batch, dtype, st);
+  return launch_gemm_dt<OPM_DENSE_MN, OPM_DENSE_MN>(p, batch, dtype, st);
+}

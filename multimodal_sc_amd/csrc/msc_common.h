@@ -1,0 +1,120 @@
+// msc_common.h — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wave = 64 lanes everywhere in this tree; nothing here is meant to build for another target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/msc.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits; arithmetic always happens in f32
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define MSC_WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even; the plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct msc_traits;
+template <> struct msc_traits<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte chunk
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct msc_traits<bf16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16-byte vector of T unpacked to floats
+template <typename T> struct vecf;
+template <> struct vecf<float> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct vecf<bf16_t> {
+  float v[8];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x multiple of 64, up to 1024 threads; all threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += smem[i];
+  return r;
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case MSC_ACT_RELU: return x > 0.f ? x : 0.f;
+    case MSC_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case MSC_ACT_TANH: return tanhf(x);
+    case MSC_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    default: return x;
+  }
+}
+
+static inline int ilog2_exact(int v) {  // -1 when v is not a power of two
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+#define MSC_CHECK_ARG(cond) \
+  do {                      \
+    if (!(cond)) return MSC_ERR_BAD_ARG; \
+  } while (0)
+
+static inline int msc_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,139 @@
+// pillar.hip — LiDAR / BEV encoder front end: per-point MLP (4 -> C, ReLU) + scatter-max into a BEV grid.
+//   feat[p][c] = relu(w[c] . point[p] + bias[c]);  grid[b][iy][ix][c] = max over points in the cell (empty = 0)
+// One wave per point, lane = channel (C = 64): the 64 atomic-max of a point hit one 256-B line.
+// Max is order-independent, so the int-compare atomicMax on non-negative floats is bitwise reproducible.
+// Backward routes d(grid) to the arg-max point(s) and reduces dW/db with fixed-order partials.
+// HBM-bound gather/scatter.  Build-authored; the upstream reference has no code.
+#include "msc_common.h"
+
+#define PIL_C 64
+#define PIL_BLOCKS 512
+
+__device__ __forceinline__ int pillar_cell(float x, float y, float lo, float cell, int G) {
+  const float fx = floorf((x - lo) / cell), fy = floorf((y - lo) / cell);
+  if (!(fx >= 0.f && fx < (float)G && fy >= 0.f && fy < (float)G)) return -1;
+  return (int)fy * G + (int)fx;
+}
+
+__global__ __launch_bounds__(256) void pillar_scatter_kernel(const float* __restrict__ pts, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ grid,
+                                                             long npts_total, int Np, int G, float lo, float cell) {
+  const int lane = threadIdx.x & 63;
+  const float w0 = w[lane * 4 + 0], w1 = w[lane * 4 + 1], w2 = w[lane * 4 + 2], w3 = w[lane * 4 + 3], bb = bias[lane];
+  const long nw = (long)gridDim.x * 4;
+  for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npts_total; p += nw) {
+    const float4 pt = *reinterpret_cast<const float4*>(pts + p * 4);
+    const int c = pillar_cell(pt.x, pt.y, lo, cell, G);
+    if (c < 0) continue;
+    const float f = fmaf(w3, pt.w, fmaf(w2, pt.z, fmaf(w1, pt.y, w0 * pt.x))) + bb;
+    if (f > 0.f) {
+      const long b = p / Np;
+      atomicMax(reinterpret_cast<int*>(grid + ((b * G * G + c) * PIL_C + lane)), __float_as_int(f));
+    }
+  }
+}
+
+// partial[blk][c][5] = sum over the block's points of g * (x,y,z,i,1) where g = dgrid at the arg-max
+template <typename T>
+__global__ __launch_bounds__(256) void pillar_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ grid,
+                                                         const T* __restrict__ dgrid, float* __restrict__ partial,
+                                                         long npts_total, int Np, int G, float lo, float cell) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float w0 = w[lane * 4 + 0], w1 = w[lane * 4 + 1], w2 = w[lane * 4 + 2], w3 = w[lane * 4 + 3], bb = bias[lane];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+  const long nw = (long)gridDim.x * 4;
+  for (long p = (long)blockIdx.x * 4 + wave; p < npts_total; p += nw) {
+    const float4 pt = *reinterpret_cast<const float4*>(pts + p * 4);
+    const int c = pillar_cell(pt.x, pt.y, lo, cell, G);
+    if (c < 0) continue;
+    const float f = fmaf(w3, pt.w, fmaf(w2, pt.z, fmaf(w1, pt.y, w0 * pt.x))) + bb;
+    const long b = p / Np;
+    const long o = (b * G * G + c) * PIL_C + lane;
+    if (f > 0.f && f == grid[o]) {
+      const float g = msc_traits<T>::ld(dgrid + o);
+      a0 += g * pt.x; a1 += g * pt.y; a2 += g * pt.z; a3 += g * pt.w; a4 += g;
+    }
+  }
+  __shared__ float red[4][PIL_C][5];
+  red[wave][lane][0] = a0; red[wave][lane][1] = a1; red[wave][lane][2] = a2; red[wave][lane][3] = a3; red[wave][lane][4] = a4;
+  __syncthreads();
+  for (int i = threadIdx.x; i < PIL_C * 5; i += 256) {
+    const int c = i / 5, k = i % 5;
+    partial[(long)blockIdx.x * PIL_C * 5 + i] = red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k];
+  }
+}
+
+__global__ void pillar_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PIL_C * 5) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += partial[(long)k * PIL_C * 5 + i];
+  const int c = i / 5, j = i % 5;
+  float* dst = j < 4 ? dw + c * 4 + j : db + c;
+  *dst = (accumulate ? *dst : 0.f) + s;
+}
+
+template <typename T>
+__global__ void grid_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long nvec) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    vecf<T> v;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v.v[j] = src[i * VEC + j];
+    v.store(dst + i * VEC);
+  }
+}
+
+// points: fp32 [B][Np][4] (x,y,z,intensity); w: fp32 [64][4]; bias fp32 [64]
+// grid_f32: fp32 [B][G][G][64] (zeroed here, kept for backward); grid_out: T copy fed to the BEV convs
+extern "C" int msc_pillar_fwd(const float* points, const float* w, const float* bias, float* grid_f32, void* grid_out, int B, int Np,
+                              int G, int C, float range_lo, float cell, int dtype, void* stream) {
+  MSC_CHECK_ARG(points && w && bias && grid_f32 && B > 0 && Np > 0 && G > 0 && C == PIL_C && cell > 0.f);
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * G * G * C;
+  if (hipMemsetAsync(grid_f32, 0, n * 4, st) != hipSuccess) return MSC_ERR_LAUNCH;
+  const long npts = (long)B * Np;
+  int blocks = cdiv(npts, 4 * 8);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pillar_scatter_kernel, dim3(blocks), dim3(256), 0, st, points, w, bias, grid_f32, npts, Np, G, range_lo, cell);
+  if (grid_out && dtype == MSC_BF16) {
+    long nb = (n / 8 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(grid_cast_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, grid_f32, (bf16_t*)grid_out, n / 8);
+  } else if (grid_out && dtype == MSC_F32 && grid_out != (void*)grid_f32) {
+    if (hipMemcpyAsync(grid_out, grid_f32, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return MSC_ERR_LAUNCH;
+  }
+  return msc_launch_status();
+}
+
+extern "C" int64_t msc_pillar_bwd_workspace_bytes(void) { return (int64_t)PIL_BLOCKS * PIL_C * 5 * 4; }
+
+extern "C" int msc_pillar_bwd(const float* points, const float* w, const float* bias, const float* grid_f32, const void* dgrid,
+                              float* dw, float* db, float* ws, int B, int Np, int G, int C, float range_lo, float cell, int accumulate,
+                              int dtype, void* stream) {
+  MSC_CHECK_ARG(points && w && bias && grid_f32 && dgrid && dw && db && ws && B > 0 && Np > 0 && G > 0 && C == PIL_C);
+  hipStream_t st = (hipStream_t)stream;
+  const long npts = (long)B * Np;
+  int blocks = cdiv(npts, 4 * 16);
+  if (blocks > PIL_BLOCKS) blocks = PIL_BLOCKS;
+  if (dtype == MSC_F32)
+    hipLaunchKernelGGL(pillar_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, points, w, bias, grid_f32, (const float*)dgrid, ws, npts, Np, G, range_lo, cell);
+  else if (dtype == MSC_BF16)
+    hipLaunchKernelGGL(pillar_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, points, w, bias, grid_f32, (const bf16_t*)dgrid, ws, npts, Np, G, range_lo, cell);
+  else
+    return MSC_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pillar_bwd_finalize_kernel, dim3(cdiv(PIL_C * 5, 64)), dim3(64), 0, st, ws, blocks, dw, db, accumulate);
+  return msc_launch_status();
+}
+
+extern "C" const char* msc_strerror(int code) {
+  switch (code) {
+    case MSC_OK: return "ok";
+    case MSC_ERR_BAD_ARG: return "bad argument (null pointer, size or alignment the kernel does not support)";
+    case MSC_ERR_LAUNCH: return "HIP launch failed";
+    case MSC_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+extern "C" int msc_version(void) { return 100; }

@@ -1,0 +1,384 @@
+"""autograd.Function wrappers over the C-ABI kernels (include/msc.h).
+
+Activations flow through torch.autograd (tensors of the runtime storage dtype); parameter gradients do NOT:
+every backward writes dW/db straight into the flat fp32 gradient buffer through ParamRef.g, so autograd never
+allocates or adds parameter gradients.  Residual-branch gradients are folded into the producing kernel
+(conv dgrad `res`, LayerNorm backward `dadd`) instead of separate add kernels.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import lib as L
+from .runtime import ParamRef, Runtime
+
+BN_EPS = 1e-5
+LN_EPS = 1e-5
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+# ------------------------------------------------------------------------------------------------ conv + BN (+ReLU)
+def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad, relu):
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = conv.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    M = B * Ho * Wo
+    nblk = _cdiv(M, 128)
+    y_raw = rt.empty(B, Ho, Wo, Cout)
+    partial = rt.workspace("bn_partial", nblk * 2 * Cout * 4)
+    rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.dt)
+    mean, rstd = rt.f32(Cout), rt.f32(Cout)
+    rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, mean, rstd)
+    y = rt.empty(B, Ho, Wo, Cout)
+    rt.call("msc_bn_apply", y_raw, mean, rstd, gamma.p, beta.p, res, y, M, Cout, int(relu), rt.dt)
+    return y, y_raw, mean, rstd
+
+
+def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, mean, rstd, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad,
+                relu, want_dres, need_dx, dx_res=None):
+    """-> (dx or None, dres or None).  dx_res: extra gradient w.r.t. x added inside the dgrad epilogue."""
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = conv.shape
+    M = y_raw.numel() // Cout
+    d_raw = torch.empty_like(y_raw)
+    dres = torch.empty_like(y_raw) if want_dres else None
+    ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
+    rt.call("msc_bn_bwd", dy, y_raw, y, mean, rstd, gamma.p, d_raw, dres, gamma.g, beta.g, ws, M, Cout, int(relu),
+            rt.accumulate, rt.dt)
+    wsb = L.query("msc_wgrad_workspace_bytes", Cout, KH * KW * Cin, M)
+    wsw = rt.workspace("wgrad", wsb)
+    rt.call("msc_conv2d_wgrad", x, d_raw, conv.g, wsw, wsb, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.accumulate, rt.dt)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        rt.call("msc_conv2d_dgrad", d_raw, conv.t, dx_res, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.dt)
+    return dx, dres
+
+
+class ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, rt, conv, gamma, beta, stride, pad, relu, need_dx):
+        # anchor: any tensor with requires_grad=True; keeps this node in the graph when x needs no gradient
+        y, y_raw, mean, rstd = conv_bn_fwd(rt, x, None, conv, gamma, beta, stride, pad, relu)
+        ctx.save_for_backward(x, y_raw, y, mean, rstd)
+        ctx.cfg = (rt, conv, gamma, beta, stride, pad, relu, need_dx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y_raw, y, mean, rstd = ctx.saved_tensors
+        rt, conv, gamma, beta, stride, pad, relu, need_dx = ctx.cfg
+        dx, _ = conv_bn_bwd(rt, dy.contiguous(), x, y_raw, y, mean, rstd, conv, gamma, beta, stride, pad, relu, False, need_dx)
+        return (dx,) + (None,) * 9
+
+
+class BasicBlockFn(torch.autograd.Function):
+    """ResNet BasicBlock as ONE autograd node: conv-bn-relu, conv-bn, (+1x1 conv-bn identity), add, relu."""
+
+    @staticmethod
+    def forward(ctx, x, rt, p, stride):
+        # p: dict of ParamRefs: conv1,bn1g,bn1b,conv2,bn2g,bn2b[,dconv,dbng,dbnb]
+        o1, o1_raw, m1, r1 = conv_bn_fwd(rt, x, None, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True)
+        has_ds = "dconv" in p
+        if has_ds:
+            idt, idt_raw, md, rd = conv_bn_fwd(rt, x, None, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False)
+        else:
+            idt = x
+        y, o2_raw, m2, r2 = conv_bn_fwd(rt, o1, idt, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True)
+        saved = [x, o1_raw, o1, m1, r1, o2_raw, y, m2, r2]
+        if has_ds:
+            saved += [idt_raw, md, rd]
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (rt, p, stride, has_ds)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, p, stride, has_ds = ctx.cfg
+        sv = ctx.saved_tensors
+        x, o1_raw, o1, m1, r1, o2_raw, y, m2, r2 = sv[:9]
+        # conv2/bn2: dres = gradient of the identity branch (post-ReLU mask)
+        do1, didt = conv_bn_bwd(rt, dy.contiguous(), o1, o2_raw, y, m2, r2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True, True, True)
+        if has_ds:
+            idt_raw, md, rd = sv[9:]
+            dx_id, _ = conv_bn_bwd(rt, didt, x, idt_raw, None, md, rd, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False, False, True)
+        else:
+            dx_id = didt
+        dx, _ = conv_bn_bwd(rt, do1, x, o1_raw, o1, m1, r1, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True, False, True, dx_res=dx_id)
+        return dx, None, None, None
+
+
+class MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rt, K, S, P):
+        B, H, W, C = x.shape
+        Ho, Wo = (H + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1
+        y = rt.empty(B, Ho, Wo, C)
+        idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+        rt.call("msc_maxpool_fwd", x, y, idx, B, H, W, C, K, S, P, rt.dt)
+        ctx.save_for_backward(idx)
+        ctx.cfg = (rt, x.shape, K, S, P)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        rt, shp, K, S, P = ctx.cfg
+        B, H, W, C = shp
+        dx = rt.empty(*shp)
+        rt.call("msc_maxpool_bwd", dy.contiguous(), idx, dx, B, H, W, C, K, S, P, rt.dt)
+        return dx, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ dense layers
+def linear_fwd(rt: Runtime, x2d, w: ParamRef, b: ParamRef, act=L.ACT_NONE, res=None, want_pre=False):
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = rt.empty(M, N)
+    pre = rt.empty(M, N) if want_pre else None
+    rt.call("msc_linear_fwd", x2d, w.c, b.p if b is not None else None, res, y, pre, M, N, K, act, rt.dt)
+    return y, pre
+
+
+def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_dx=True):
+    """dy2d: gradient w.r.t. the layer output (after activation). ref: y (relu/tanh/sigmoid) or pre (gelu)."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    if act != L.ACT_NONE:
+        d = torch.empty_like(dy2d)
+        rt.call("msc_act_bwd", dy2d, ref, d, M * N, act, rt.dt)
+    else:
+        d = dy2d
+    if b is not None:
+        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", N))
+        rt.call("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)
+    wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
+    wsw = rt.workspace("wgrad", wsb)
+    rt.call("msc_linear_wgrad", x2d, d, w.g, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
+    dx = None
+    if need_dx:
+        dx = rt.empty(M, K)
+        rt.call("msc_linear_dgrad", d, w.t, dx, M, N, K, rt.dt)
+    return dx
+
+
+class Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, rt, w, b, act, need_dx):
+        x2d = x.reshape(-1, x.shape[-1])
+        y, pre = linear_fwd(rt, x2d, w, b, act, None, want_pre=(act == L.ACT_GELU))
+        ctx.save_for_backward(x2d, pre if act == L.ACT_GELU else (y if act != L.ACT_NONE else None))
+        ctx.cfg = (rt, w, b, act, need_dx, x.shape)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, ref = ctx.saved_tensors
+        rt, w, b, act, need_dx, shp = ctx.cfg
+        dx = linear_bwd(rt, dy.reshape(-1, dy.shape[-1]).contiguous(), x2d, ref, w, b, act, need_dx)
+        return (dx.view(shp) if dx is not None else None), None, None, None, None, None, None
+
+
+def layernorm_fwd(rt, x2d, g: ParamRef, b: ParamRef):
+    R, D = x2d.shape
+    y = torch.empty_like(x2d)
+    mean, rstd = rt.f32(R), rt.f32(R)
+    rt.call("msc_layernorm_fwd", x2d, g.p, b.p, y, mean, rstd, R, D, LN_EPS, rt.dt)
+    return y, mean, rstd
+
+
+def layernorm_bwd(rt, dy2d, x2d, mean, rstd, g: ParamRef, b: ParamRef, dadd=None):
+    R, D = x2d.shape
+    dx = torch.empty_like(x2d)
+    ws = rt.workspace("ln_bwd", L.query("msc_layernorm_bwd_workspace_bytes", R, D))
+    rt.call("msc_layernorm_bwd", dy2d, x2d, mean, rstd, g.p, dadd, dx, g.g, b.g, ws, R, D, rt.accumulate, rt.dt)
+    return dx
+
+
+class LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rt, g, b):
+        x2d = x.reshape(-1, x.shape[-1])
+        y, mean, rstd = layernorm_fwd(rt, x2d, g, b)
+        ctx.save_for_backward(x2d, mean, rstd)
+        ctx.cfg = (rt, g, b, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, mean, rstd = ctx.saved_tensors
+        rt, g, b, shp = ctx.cfg
+        dx = layernorm_bwd(rt, dy.reshape(-1, dy.shape[-1]).contiguous(), x2d, mean, rstd, g, b)
+        return dx.view(shp), None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ attention (unfused v1)
+def attention_fwd(rt: Runtime, qkv, B, T, h, hd):
+    """qkv: [B*T, 3*h*hd] (q|k|v, heads inside). -> o [B*T, h*hd], P [B*h, T, Tp]"""
+    D = h * hd
+    Tp = _cdiv(T, 64) * 64
+    S = rt.workspace("attn_scores", B * h * T * Tp * 4)
+    q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
+    ld = 3 * D
+    scale = 1.0 / math.sqrt(hd)
+    rt.call("msc_gemm_batched", q, k, S, T, T, hd, ld, ld, Tp, 1, 1, B * h, h, T * ld, hd, T * ld, hd, h * T * Tp, T * Tp,
+            scale, 1, rt.dt)
+    P = rt.empty(B * h, T, Tp)
+    rt.call("msc_softmax_fwd", S, P, B * h * T, T, Tp, rt.dt)
+    o = rt.empty(B * T, D)
+    rt.call("msc_gemm_batched", P, v, o, T, hd, T, Tp, ld, D, 1, 0, B * h, h, h * T * Tp, T * Tp, T * ld, hd, T * D, hd,
+            1.0, 0, rt.dt)
+    return o, P
+
+
+def attention_bwd(rt: Runtime, do, qkv, P, B, T, h, hd):
+    D = h * hd
+    Tp = P.shape[-1]
+    ld = 3 * D
+    q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
+    scale = 1.0 / math.sqrt(hd)
+    dqkv = rt.empty(B * T, 3 * D)
+    dq, dk, dv = dqkv, dqkv[:, D:], dqkv[:, 2 * D:]
+    nb = B * h
+    # dV[key][d] = sum_q P[q][key] dO[q][d]
+    rt.call("msc_gemm_batched", P, do, dv, T, hd, T, Tp, D, ld, 0, 0, nb, h, h * T * Tp, T * Tp, T * D, hd, T * ld, hd, 1.0, 0, rt.dt)
+    # dP[q][key] = sum_d dO[q][d] V[key][d]
+    dP = rt.workspace("attn_scores", nb * T * Tp * 4)
+    rt.call("msc_gemm_batched", do, v, dP, T, T, hd, D, ld, Tp, 1, 1, nb, h, T * D, hd, T * ld, hd, h * T * Tp, T * Tp, 1.0, 1, rt.dt)
+    dS = torch.empty_like(P)
+    rt.call("msc_softmax_bwd", dP, P, dS, nb * T, T, Tp, rt.dt)
+    # dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
+    rt.call("msc_gemm_batched", dS, k, dq, T, hd, T, Tp, ld, ld, 1, 0, nb, h, h * T * Tp, T * Tp, T * ld, hd, T * ld, hd, scale, 0, rt.dt)
+    # dK[key][d] = scale * sum_q dS[q][key] Q[q][d]
+    rt.call("msc_gemm_batched", dS, q, dk, T, hd, T, Tp, ld, ld, 0, 0, nb, h, h * T * Tp, T * Tp, T * ld, hd, T * ld, hd, scale, 0, rt.dt)
+    return dqkv
+
+
+class FusionLayerFn(torch.autograd.Function):
+    """One pre-LN transformer block as ONE autograd node (LN -> QKV -> attention -> proj(+x) -> LN -> FFN(+x))."""
+
+    @staticmethod
+    def forward(ctx, x, rt, p, h):
+        B, T, D = x.shape
+        hd = D // h
+        x2d = x.reshape(B * T, D)
+        h1, mu1, rs1 = layernorm_fwd(rt, x2d, p["ln1g"], p["ln1b"])
+        qkv, _ = linear_fwd(rt, h1, p["qkvw"], p["qkvb"])
+        o, P = attention_fwd(rt, qkv, B, T, h, hd)
+        x1, _ = linear_fwd(rt, o, p["projw"], p["projb"], L.ACT_NONE, res=x2d)
+        h2, mu2, rs2 = layernorm_fwd(rt, x1, p["ln2g"], p["ln2b"])
+        u, upre = linear_fwd(rt, h2, p["fc1w"], p["fc1b"], L.ACT_GELU, want_pre=True)
+        x2, _ = linear_fwd(rt, u, p["fc2w"], p["fc2b"], L.ACT_NONE, res=x1)
+        ctx.save_for_backward(x2d, mu1, rs1, h1, qkv, P, o, x1, mu2, rs2, h2, upre, u)
+        ctx.cfg = (rt, p, h, (B, T, D))
+        return x2.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, p, h, (B, T, D) = ctx.cfg
+        hd = D // h
+        x2d, mu1, rs1, h1, qkv, P, o, x1, mu2, rs2, h2, upre, u = ctx.saved_tensors
+        dx2 = dy.reshape(B * T, D).contiguous()
+        du = linear_bwd(rt, dx2, u, None, p["fc2w"], p["fc2b"], L.ACT_NONE)
+        dh2 = linear_bwd(rt, du, h2, upre, p["fc1w"], p["fc1b"], L.ACT_GELU)
+        dx1 = layernorm_bwd(rt, dh2, x1, mu2, rs2, p["ln2g"], p["ln2b"], dadd=dx2)       # + residual branch
+        do = linear_bwd(rt, dx1, o, None, p["projw"], p["projb"], L.ACT_NONE)
+        dqkv = attention_bwd(rt, do, qkv, P, B, T, h, hd)
+        dh1 = linear_bwd(rt, dqkv, h1, None, p["qkvw"], p["qkvb"], L.ACT_NONE)
+        dx = layernorm_bwd(rt, dh1, x2d, mu1, rs1, p["ln1g"], p["ln1b"], dadd=dx1)
+        return dx.view(B, T, D), None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ tokens / pooling
+class TokensAssemble(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s0, s1, s2, rt, pos: ParamRef):
+        B, n0, D = s0.shape
+        n1 = s1.shape[1] if s1 is not None else 0
+        n2 = s2.shape[1] if s2 is not None else 0
+        out = rt.empty(B, n0 + n1 + n2, D)
+        rt.call("msc_tokens_assemble", s0, s1, s2, pos.p, out, B, n0, n1, n2, D, rt.dt)
+        ctx.cfg = (rt, pos, B, n0, n1, n2, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rt, pos, B, n0, n1, n2, D = ctx.cfg
+        dout = dout.contiguous()
+        d0 = rt.empty(B, n0, D)
+        d1 = rt.empty(B, n1, D) if n1 else None
+        d2 = rt.empty(B, n2, D) if n2 else None
+        rt.call("msc_tokens_split", dout, d0, d1, d2, B, n0, n1, n2, D, rt.dt)
+        cols = (n0 + n1 + n2) * D
+        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", cols))
+        rt.call("msc_colsum", dout, pos.g, ws, B, cols, rt.accumulate, rt.dt)
+        return d0, d1, d2, None, None
+
+
+class MeanPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rt):
+        B, T, D = x.shape
+        y = rt.empty(B, D)
+        rt.call("msc_meanpool_fwd", x, y, B, T, D, rt.dt)
+        ctx.cfg = (rt, B, T, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, B, T, D = ctx.cfg
+        dx = rt.empty(B, T, D)
+        rt.call("msc_meanpool_bwd", dy.contiguous(), dx, B, T, D, rt.dt)
+        return dx, None
+
+
+# ------------------------------------------------------------------------------------------------ channel
+class ChannelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rt, snr_db, noise, fading, mode, seed):
+        B, k = x.shape
+        y = rt.empty(B, k)
+        scale = rt.f32(B)
+        rt.call("msc_channel_fwd", x, noise, fading, snr_db, y, scale, B, k, mode, int(seed), rt.dt)
+        ctx.save_for_backward(x, scale)
+        ctx.rt = rt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale = ctx.saved_tensors
+        rt = ctx.rt
+        dx = torch.empty_like(x)
+        rt.call("msc_channel_bwd", dy.contiguous(), x, scale, dx, x.shape[0], x.shape[1], rt.dt)
+        return dx, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ LiDAR pillars
+class PillarFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, anchor, rt, w: ParamRef, b: ParamRef, G, rng):
+        B, Np, _ = points.shape
+        C = w.shape[0]
+        cell = 2.0 * rng / G
+        grid32 = rt.f32(B, G, G, C)
+        out = grid32 if rt.dt == L.MSC_F32 else rt.empty(B, G, G, C)
+        rt.call("msc_pillar_fwd", points, w.p, b.p, grid32, out, B, Np, G, C, -rng, cell, rt.dt)
+        ctx.save_for_backward(points, grid32)
+        ctx.cfg = (rt, w, b, G, rng, cell)
+        return out
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        points, grid32 = ctx.saved_tensors
+        rt, w, b, G, rng, cell = ctx.cfg
+        B, Np, _ = points.shape
+        ws = rt.workspace("pillar", L.query("msc_pillar_bwd_workspace_bytes"))
+        rt.call("msc_pillar_bwd", points, w.p, b.p, grid32, dgrid.contiguous(), w.g, b.g, ws, B, Np, G, w.shape[0], -rng, cell,
+                rt.accumulate, rt.dt)
+        return None, None, None, None, None, None, None

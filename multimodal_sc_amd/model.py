@@ -1,0 +1,346 @@
+"""MultimodalSC on MI355X: the Python model surface (names from BASELINE.json `north_star`) over the HIP kernels.
+
+The upstream reference ships no code (SURVEY.md finding zero), so the "reference Python API" this mirrors is the
+module/state_dict naming of the build-authored oracle (oracle/model.py): same keys, same forward signature
+`model(image, points, state, snr_db, noise, fading)`.  Conv weights are held OHWI (channels-last) and the
+policy/value output layers are packed into one [16,hidden] matrix; load_oracle_state_dict/export_state_dict
+convert.  Nothing in this file runs math on the CPU or through torch ops: every layer is a C-ABI kernel call.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import functional as F
+from . import lib as L
+from .runtime import ParamStore, Runtime
+
+
+@dataclass
+class MSCConfig:
+    img_size: int = 224
+    use_lidar: bool = True
+    use_state: bool = True
+    n_points: int = 16384
+    bev_grid: int = 128
+    bev_range: float = 51.2
+    point_feat: int = 64
+    state_dim: int = 8
+    d_model: int = 512
+    n_heads: int = 8
+    n_layers: int = 4
+    ffn: int = 2048
+    n_symbols: int = 256
+    n_actions: int = 9
+    head_hidden: int = 256
+    patch: int = 32
+    recon_hidden: int = 64
+    channel: str = "awgn"
+    clip_eps: float = 0.2
+    c_value: float = 0.5
+    c_entropy: float = 0.01
+    recon_weight: float = 1.0
+
+    @property
+    def img_tokens(self):
+        return (self.img_size // 32) ** 2
+
+    @property
+    def bev_tokens(self):
+        return (self.bev_grid // 8) ** 2 if self.use_lidar else 0
+
+    @property
+    def n_tokens(self):
+        return self.img_tokens + self.bev_tokens + (1 if self.use_state else 0)
+
+    @property
+    def recon_grid(self):
+        return self.img_size // self.patch
+
+
+def named_config(name: str) -> MSCConfig:
+    name = name.upper()
+    table = {
+        "C0": dict(img_size=32, use_lidar=False, use_state=False),
+        "C1": dict(img_size=224, use_lidar=False, use_state=False),
+        "C2": dict(img_size=224, use_lidar=True, use_state=False),
+        "C3": dict(img_size=224, use_lidar=True, use_state=True),
+        "C4": dict(img_size=224, use_lidar=True, use_state=True, channel="rayleigh"),
+    }
+    return MSCConfig(**table[name])
+
+
+HEAD_PAD = 16   # policy logits (n_actions) + value (1) packed and zero-padded to 16 output rows
+IMG_CPAD = 8    # RGB padded to 8 channels so every implicit-GEMM K chunk is a full 16-byte vector
+
+
+def _resnet_specs():
+    specs = [("image_encoder.conv1.weight", (64, 7, 7, IMG_CPAD), "conv"),
+             ("image_encoder.bn1.weight", (64,), "vec"), ("image_encoder.bn1.bias", (64,), "vec")]
+    chans = [64, 64, 128, 256, 512]
+    for li in range(1, 5):
+        for bi in range(2):
+            cin = chans[li - 1] if bi == 0 else chans[li]
+            cout = chans[li]
+            pre = f"image_encoder.layer{li}.{bi}"
+            specs += [(f"{pre}.conv1.weight", (cout, 3, 3, cin), "conv"), (f"{pre}.bn1.weight", (cout,), "vec"),
+                      (f"{pre}.bn1.bias", (cout,), "vec"), (f"{pre}.conv2.weight", (cout, 3, 3, cout), "conv"),
+                      (f"{pre}.bn2.weight", (cout,), "vec"), (f"{pre}.bn2.bias", (cout,), "vec")]
+            if bi == 0 and li > 1:
+                specs += [(f"{pre}.downsample.0.weight", (cout, 1, 1, cin), "conv"),
+                          (f"{pre}.downsample.1.weight", (cout,), "vec"), (f"{pre}.downsample.1.bias", (cout,), "vec")]
+    return specs
+
+
+def param_specs(cfg: MSCConfig):
+    d = cfg.d_model
+    specs = _resnet_specs()
+    if cfg.use_lidar:
+        specs += [("bev_encoder.point_mlp.weight", (cfg.point_feat, 4), "vec"), ("bev_encoder.point_mlp.bias", (cfg.point_feat,), "vec")]
+        cc = [cfg.point_feat, 128, 256, d]
+        for i in range(1, 4):
+            specs += [(f"bev_encoder.conv{i}.weight", (cc[i], 3, 3, cc[i - 1]), "conv"),
+                      (f"bev_encoder.bn{i}.weight", (cc[i],), "vec"), (f"bev_encoder.bn{i}.bias", (cc[i],), "vec")]
+    if cfg.use_state:
+        specs += [("state_encoder.fc1.weight", (d, cfg.state_dim), "linear"), ("state_encoder.fc1.bias", (d,), "vec"),
+                  ("state_encoder.fc2.weight", (d, d), "linear"), ("state_encoder.fc2.bias", (d,), "vec")]
+    specs += [("fusion.pos_embed", (cfg.n_tokens, d), "vec")]
+    for i in range(cfg.n_layers):
+        pre = f"fusion.layers.{i}"
+        specs += [(f"{pre}.ln1.weight", (d,), "vec"), (f"{pre}.ln1.bias", (d,), "vec"),
+                  (f"{pre}.attn.qkv.weight", (3 * d, d), "linear"), (f"{pre}.attn.qkv.bias", (3 * d,), "vec"),
+                  (f"{pre}.attn.proj.weight", (d, d), "linear"), (f"{pre}.attn.proj.bias", (d,), "vec"),
+                  (f"{pre}.ln2.weight", (d,), "vec"), (f"{pre}.ln2.bias", (d,), "vec"),
+                  (f"{pre}.mlp.fc1.weight", (cfg.ffn, d), "linear"), (f"{pre}.mlp.fc1.bias", (cfg.ffn,), "vec"),
+                  (f"{pre}.mlp.fc2.weight", (d, cfg.ffn), "linear"), (f"{pre}.mlp.fc2.bias", (d,), "vec")]
+    specs += [("fusion.ln_f.weight", (d,), "vec"), ("fusion.ln_f.bias", (d,), "vec")]
+    specs += [("semantic_encoder.fc1.weight", (d, d), "linear"), ("semantic_encoder.fc1.bias", (d,), "vec"),
+              ("semantic_encoder.fc2.weight", (cfg.n_symbols, d), "linear"), ("semantic_encoder.fc2.bias", (cfg.n_symbols,), "vec"),
+              ("semantic_decoder.fc1.weight", (d, cfg.n_symbols), "linear"), ("semantic_decoder.fc1.bias", (d,), "vec"),
+              ("semantic_decoder.fc2.weight", (d, d), "linear"), ("semantic_decoder.fc2.bias", (d,), "vec"),
+              ("head.fc.weight", (cfg.head_hidden, d), "linear"), ("head.fc.bias", (cfg.head_hidden,), "vec"),
+              ("head.out.weight", (HEAD_PAD, cfg.head_hidden), "linear"), ("head.out.bias", (HEAD_PAD,), "vec")]
+    g = cfg.recon_grid
+    specs += [("recon.fc1.weight", (g * g * cfg.recon_hidden, d), "linear"), ("recon.fc1.bias", (g * g * cfg.recon_hidden,), "vec"),
+              ("recon.fc2.weight", (cfg.patch * cfg.patch * 3, cfg.recon_hidden), "linear"),
+              ("recon.fc2.bias", (cfg.patch * cfg.patch * 3,), "vec")]
+    return specs
+
+
+class MultimodalSC:
+    """Camera + LiDAR/BEV + ego-state encoders -> fusion transformer -> semantic encoder -> channel -> decoder ->
+    policy/value head + reconstruction head, every layer a hand-written gfx950 kernel."""
+
+    def __init__(self, cfg: MSCConfig, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0):
+        assert cfg.n_actions + 1 <= HEAD_PAD
+        self.cfg = cfg
+        self.rt = Runtime(dtype, device)
+        self.params = ParamStore(self.rt, param_specs(cfg))
+        self.anchor = torch.zeros(1, device=self.rt.device, requires_grad=True)
+        self.channel_seed = 0
+        self._init_params(seed)
+
+    # ------------------------------------------------------------------ parameters
+    def _init_params(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        for r in self.params.refs.values():
+            if r.name.endswith("bn1.weight") or r.name.endswith("bn2.weight") or r.name.endswith("bn3.weight") or \
+               r.name.endswith("downsample.1.weight") or ".ln" in r.name and r.name.endswith("weight") or r.name.endswith("ln_f.weight"):
+                v = torch.ones(r.shape)
+            elif r.name.endswith("bias"):
+                v = torch.zeros(r.shape)
+            elif r.name == "fusion.pos_embed":
+                v = torch.randn(r.shape, generator=g) * 0.02
+            else:
+                fan_in = 1
+                for s in r.shape[1:]:
+                    fan_in *= s
+                v = torch.randn(r.shape, generator=g) * math.sqrt(2.0 / fan_in) * 0.7
+            r.p.copy_(v)
+        self.params["image_encoder.conv1.weight"].p[..., 3:].zero_()
+        A = self.cfg.n_actions
+        self.params["head.out.weight"].p[A + 1:].zero_()
+        self.params.refresh_compute_copies()
+
+    def load_oracle_state_dict(self, sd):
+        """sd: state_dict of oracle.model.MultimodalSC (or any dict with the same keys/shapes, OIHW convs)."""
+        A = self.cfg.n_actions
+        for r in self.params.refs.values():
+            if r.name == "head.out.weight":
+                v = torch.zeros(r.shape)
+                v[:A] = sd["head.policy.weight"]
+                v[A] = sd["head.value.weight"][0]
+            elif r.name == "head.out.bias":
+                v = torch.zeros(r.shape)
+                v[:A] = sd["head.policy.bias"]
+                v[A] = sd["head.value.bias"][0]
+            elif r.kind == "conv":
+                w = sd[r.name].permute(0, 2, 3, 1)                       # OIHW -> OHWI
+                v = torch.zeros(r.shape)
+                v[..., : w.shape[-1]] = w
+            else:
+                v = sd[r.name]
+            r.p.copy_(v.to(torch.float32).reshape(r.shape))
+        self.params.refresh_compute_copies()
+
+    def export_state_dict(self, grads: bool = False):
+        """Back to the oracle's key names / OIHW layout (parameters, or their gradients with grads=True)."""
+        A = self.cfg.n_actions
+        out = {}
+        for r in self.params.refs.values():
+            t = (r.g if grads else r.p).detach().float().cpu()
+            if r.name == "head.out.weight":
+                out["head.policy.weight"], out["head.value.weight"] = t[:A].clone(), t[A:A + 1].clone()
+            elif r.name == "head.out.bias":
+                out["head.policy.bias"], out["head.value.bias"] = t[:A].clone(), t[A:A + 1].clone()
+            elif r.kind == "conv":
+                w = t.permute(0, 3, 1, 2)
+                out[r.name] = (w[:, :3] if r.name == "image_encoder.conv1.weight" else w).contiguous()
+            else:
+                out[r.name] = t.clone()
+        return out
+
+    # ------------------------------------------------------------------ blocks
+    def _block_params(self, pre, has_ds):
+        P = self.params
+        d = {"conv1": P[f"{pre}.conv1.weight"], "bn1g": P[f"{pre}.bn1.weight"], "bn1b": P[f"{pre}.bn1.bias"],
+             "conv2": P[f"{pre}.conv2.weight"], "bn2g": P[f"{pre}.bn2.weight"], "bn2b": P[f"{pre}.bn2.bias"]}
+        if has_ds:
+            d.update(dconv=P[f"{pre}.downsample.0.weight"], dbng=P[f"{pre}.downsample.1.weight"], dbnb=P[f"{pre}.downsample.1.bias"])
+        return d
+
+    def image_encoder(self, image):
+        """image: fp32 NCHW [B,3,H,W] in [0,1] -> tokens [B,(H/32)*(W/32),512]"""
+        rt, P = self.rt, self.params
+        B, C, H, W = image.shape
+        x = rt.empty(B, H, W, IMG_CPAD)
+        rt.call("msc_image_to_nhwc", image, x, B, C, H, W, IMG_CPAD, rt.dt)
+        x = F.ConvBNAct.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
+                              P["image_encoder.bn1.bias"], 2, 3, True, False)
+        x = F.MaxPool.apply(x, rt, 3, 2, 1)
+        for li in range(1, 5):
+            for bi in range(2):
+                has_ds = bi == 0 and li > 1
+                x = F.BasicBlockFn.apply(x, rt, self._block_params(f"image_encoder.layer{li}.{bi}", has_ds), 2 if has_ds else 1)
+        return x.view(B, -1, x.shape[-1])
+
+    def bev_encoder(self, points):
+        rt, P, cfg = self.rt, self.params, self.cfg
+        g = F.PillarFn.apply(points, self.anchor, rt, P["bev_encoder.point_mlp.weight"], P["bev_encoder.point_mlp.bias"],
+                             cfg.bev_grid, cfg.bev_range)
+        x = g
+        for i in range(1, 4):
+            x = F.ConvBNAct.apply(x, self.anchor, rt, P[f"bev_encoder.conv{i}.weight"], P[f"bev_encoder.bn{i}.weight"],
+                                  P[f"bev_encoder.bn{i}.bias"], 2, 1, True, True)
+        return x.view(x.shape[0], -1, x.shape[-1])
+
+    def state_encoder(self, state):
+        rt, P = self.rt, self.params
+        s = rt.empty(*state.shape)
+        rt.call("msc_cast", state, s, state.numel(), rt.dt)
+        h = F.Linear.apply(s, self.anchor, rt, P["state_encoder.fc1.weight"], P["state_encoder.fc1.bias"], L.ACT_RELU, False)
+        return F.Linear.apply(h, None, rt, P["state_encoder.fc2.weight"], P["state_encoder.fc2.bias"], L.ACT_NONE, True)
+
+    def fusion(self, img_tok, bev_tok, st_tok):
+        rt, P, cfg = self.rt, self.params, self.cfg
+        x = F.TokensAssemble.apply(img_tok, bev_tok, st_tok, rt, P["fusion.pos_embed"])
+        for i in range(cfg.n_layers):
+            pre = f"fusion.layers.{i}"
+            p = {"ln1g": P[f"{pre}.ln1.weight"], "ln1b": P[f"{pre}.ln1.bias"], "qkvw": P[f"{pre}.attn.qkv.weight"],
+                 "qkvb": P[f"{pre}.attn.qkv.bias"], "projw": P[f"{pre}.attn.proj.weight"], "projb": P[f"{pre}.attn.proj.bias"],
+                 "ln2g": P[f"{pre}.ln2.weight"], "ln2b": P[f"{pre}.ln2.bias"], "fc1w": P[f"{pre}.mlp.fc1.weight"],
+                 "fc1b": P[f"{pre}.mlp.fc1.bias"], "fc2w": P[f"{pre}.mlp.fc2.weight"], "fc2b": P[f"{pre}.mlp.fc2.bias"]}
+            x = F.FusionLayerFn.apply(x, rt, p, cfg.n_heads)
+        return F.LayerNorm.apply(x, rt, P["fusion.ln_f.weight"], P["fusion.ln_f.bias"])
+
+    def _lin(self, x, name, act=L.ACT_NONE):
+        P = self.params
+        return F.Linear.apply(x, None, self.rt, P[f"{name}.weight"], P[f"{name}.bias"], act, True)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, image, points=None, state=None, snr_db=None, noise=None, fading=None):
+        """Inputs are fp32 device tensors.  noise/fading None -> in-kernel Philox (throughput mode).
+        Returns dict: head [B,16] (logits 0..A-1, value at A), patches [B*G*G, P*P*3], symbols, rx, feature, z."""
+        cfg, rt = self.cfg, self.rt
+        B = image.shape[0]
+        img_tok = self.image_encoder(image)
+        bev_tok = self.bev_encoder(points) if cfg.use_lidar else None
+        st_tok = self.state_encoder(state).view(B, 1, cfg.d_model) if cfg.use_state else None
+        x = self.fusion(img_tok, bev_tok, st_tok)
+        f = F.MeanPool.apply(x, rt)
+        sym = self._lin(self._lin(f, "semantic_encoder.fc1", L.ACT_RELU), "semantic_encoder.fc2")
+        mode = L.CH_AWGN if cfg.channel == "awgn" else L.CH_RAYLEIGH
+        self.channel_seed += 1
+        rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, self.channel_seed)
+        z = self._lin(self._lin(rx, "semantic_decoder.fc1", L.ACT_RELU), "semantic_decoder.fc2")
+        head = self._lin(self._lin(z, "head.fc", L.ACT_TANH), "head.out")
+        g = cfg.recon_grid
+        r1 = self._lin(z, "recon.fc1", L.ACT_RELU).view(B * g * g, cfg.recon_hidden)
+        patches = self._lin(r1, "recon.fc2", L.ACT_SIGMOID)
+        return {"head": head, "patches": patches, "symbols": sym, "rx": rx, "feature": f, "z": z}
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ outputs in the oracle's format
+    def logits_value(self, out):
+        A = self.cfg.n_actions
+        h = out["head"].float()
+        return h[:, :A], h[:, A]
+
+    def select_action(self, out):
+        """arg-max over the action logits, lowest index on ties (int64, bit-exact integer output)."""
+        rt = self.rt
+        B = out["head"].shape[0]
+        act = torch.empty(B, dtype=torch.int64, device=rt.device)
+        rt.call("msc_argmax_rows", out["head"], act, B, self.cfg.n_actions, HEAD_PAD, rt.dt)
+        return act
+
+    def recon_image(self, out):
+        rt, cfg = self.rt, self.cfg
+        B = out["head"].shape[0]
+        img = rt.f32(B, 3, cfg.img_size, cfg.img_size)
+        rt.call("msc_unpatchify", out["patches"], img, B, cfg.recon_grid, cfg.patch, rt.dt)
+        return img
+
+    # ------------------------------------------------------------------ loss + backward
+    def loss_and_grads(self, out, image, ppo=None, backward=True):
+        """Fused loss kernels produce the loss terms AND d(loss)/d(head), d(loss)/d(patches); autograd then runs
+        the kernel backward chain from those two gradients.  Returns dict of fp32 device scalars."""
+        rt, cfg = self.rt, self.cfg
+        B = image.shape[0]
+        g, P = cfg.recon_grid, cfg.patch
+        n_el = 3 * cfg.img_size * cfg.img_size
+        sse = rt.f32(B)
+        dpat = torch.empty_like(out["patches"])
+        ws = rt.workspace("recon_loss", L.query("msc_recon_loss_workspace_bytes", B))
+        rt.call("msc_recon_loss", out["patches"], image, sse, dpat, ws, B, g, P, 2.0 * cfg.recon_weight / (B * n_el), rt.dt)
+        terms = {"sse": sse}
+        dhead = None
+        if ppo is not None:
+            t = rt.f32(4)
+            dhead = torch.empty_like(out["head"])
+            rt.call("msc_ppo_loss", out["head"], ppo["actions"], ppo["old_logp"], ppo["adv"], ppo["ret"], t, dhead, B,
+                    cfg.n_actions, HEAD_PAD, cfg.clip_eps, cfg.c_value, cfg.c_entropy, rt.dt)
+            terms["ppo"] = t
+        if backward:
+            if dhead is not None:
+                torch.autograd.backward([out["patches"], out["head"]], [dpat, dhead])
+            else:
+                torch.autograd.backward([out["patches"]], [dpat])
+        return terms
+
+    def metrics(self, terms):
+        """Host-side scalars (synchronises): mse, psnr (mean over samples), loss, PPO terms."""
+        cfg = self.cfg
+        n_el = 3 * cfg.img_size * cfg.img_size
+        sse = terms["sse"].double().cpu()
+        mse = float(sse.sum() / (sse.numel() * n_el))
+        psnr = float((10.0 * torch.log10(n_el / sse)).mean())
+        m = {"mse": mse, "psnr": psnr, "loss": cfg.recon_weight * mse}
+        if "ppo" in terms:
+            t = terms["ppo"].cpu()
+            m.update(ppo_total=float(t[0]), policy=float(t[1]), value=float(t[2]), entropy=float(t[3]))
+            m["loss"] += float(t[0])
+        return m

@@ -1,0 +1,115 @@
+"""Runtime context + flat parameter store for the MI355X path.
+
+Memory layout in HBM (one process per GPU):
+  P   fp32 master parameters, one flat buffer (views per tensor, 64-element aligned)
+  G   fp32 gradients, same offsets (filled directly by the wgrad / reduction kernels, no autograd adds)
+  C   compute copies in the storage dtype (bf16 mode: written by the fused Adam kernel; fp32 mode: C is P)
+  TR  transposed compute copies used by the dgrad GEMMs ([Cin][KH*KW][Cout] for convs, [in][out] for linears)
+  M,V Adam moments (fp32)
+Flat buffers make the DP all-reduce a handful of large RCCL calls and the optimizer one kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as L
+
+
+class ParamRef:
+    """Handle the kernels use: .p fp32 master, .c compute copy, .t transposed compute copy (or None), .g fp32 grad."""
+    __slots__ = ("name", "shape", "kind", "off", "numel", "p", "c", "t", "g")
+
+    def __init__(self, name, shape, kind, off):
+        self.name, self.shape, self.kind, self.off = name, tuple(shape), kind, off
+        n = 1
+        for s in shape:
+            n *= s
+        self.numel = n
+        self.p = self.c = self.t = self.g = None
+
+
+class Runtime:
+    def __init__(self, dtype: str = "bf16", device: str = "cuda:0"):
+        assert dtype in ("bf16", "f32")
+        self.dt = L.MSC_BF16 if dtype == "bf16" else L.MSC_F32
+        self.tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.vec = 8 if dtype == "bf16" else 4
+        self.device = torch.device(device)
+        self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
+        self._ws = {}
+        L.lib.load()                 # fail loudly, now, if the HIP extension is missing
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def f32(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def workspace(self, name: str, nbytes: int) -> torch.Tensor:
+        """Persistent fp32 scratch (grown on demand; sizes settle during the warm-up step before graph capture)."""
+        n = (int(nbytes) + 3) // 4
+        t = self._ws.get(name)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+            self._ws[name] = t
+        return t
+
+    def call(self, name, *args):
+        return L.call(name, *args, self.stream)
+
+
+class ParamStore:
+    ALIGN = 64
+
+    def __init__(self, rt: Runtime, specs):
+        """specs: list of (name, shape, kind) with kind in {'conv','linear','vec'}."""
+        self.rt = rt
+        self.refs = {}
+        off = 0
+        for name, shape, kind in specs:
+            r = ParamRef(name, shape, kind, off)
+            self.refs[name] = r
+            off += (r.numel + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        dev = rt.device
+        self.P = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.M = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.V = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.C = self.P if rt.dt == L.MSC_F32 else torch.zeros(off, dtype=rt.tdtype, device=dev)
+        self.TR = torch.zeros(off, dtype=rt.tdtype, device=dev)
+        for r in self.refs.values():
+            sl = slice(r.off, r.off + r.numel)
+            r.p = self.P[sl].view(r.shape)
+            r.g = self.G[sl].view(r.shape)
+            r.c = self.C[sl].view(r.shape)
+            r.t = self.TR[sl] if r.kind in ("conv", "linear") else None
+        self.step_count = 0
+
+    def __getitem__(self, name) -> ParamRef:
+        return self.refs[name]
+
+    def refresh_compute_copies(self, cast: bool = True):
+        """P -> C (bf16 mode, unless Adam already wrote the shadow) and the transposed copies TR."""
+        rt = self.rt
+        if cast and rt.dt != L.MSC_F32:
+            rt.call("msc_cast", self.P, self.C, self.total, rt.dt)
+        for r in self.refs.values():
+            if r.kind == "conv":
+                co, kh, kw, ci = r.shape
+                rt.call("msc_permute3_cast", r.p, r.t, co, kh * kw, ci, rt.dt)
+            elif r.kind == "linear":
+                n, k = r.shape
+                rt.call("msc_permute3_cast", r.p, r.t, n, 1, k, rt.dt)
+
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        rt = self.rt
+        self.step_count += 1
+        rt.call("msc_adam_step", self.P, self.G, self.M, self.V, None if rt.dt == L.MSC_F32 else self.C, self.total,
+                float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.step_count,
+                float(grad_scale), rt.dt)
+        self.refresh_compute_copies(cast=False)

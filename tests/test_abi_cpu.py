@@ -1,0 +1,144 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol include/msc.h declares (no compute
+calls without a GPU); the product path fails loudly without its extension; the oracle's known answers."""
+import ctypes
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from multimodal_sc_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.dirname(L.LIB_PATH), "-j8"], stdout=subprocess.DEVNULL)
+    return L
+
+
+def test_header_parses_and_every_symbol_is_exported(built_lib):
+    L = built_lib
+    protos = L.parse_header()
+    assert len(protos) >= 40
+    for must in ("msc_conv2d_fwd", "msc_conv2d_dgrad", "msc_conv2d_wgrad", "msc_linear_fwd", "msc_gemm_batched", "msc_channel_fwd",
+                 "msc_pillar_fwd", "msc_ppo_loss", "msc_argmax_rows", "msc_adam_step", "msc_layernorm_bwd", "msc_bn_bwd"):
+        assert must in protos
+    dll = ctypes.CDLL(L.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"{name} declared in include/msc.h but not exported by libmsc_hip.so"
+
+
+def test_library_exports_nothing_undeclared(built_lib):
+    L = built_lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("msc_")}
+    assert exported == set(L.parse_header().keys())
+
+
+def test_pure_host_entry_points(built_lib):
+    L = built_lib
+    assert L.lib.msc_version() >= 100
+    assert b"bad argument" in L.lib.msc_strerror(-1)
+    assert L.query("msc_wgrad_workspace_bytes", 64, 576, 200704) > 0
+    # argument validation happens before any HIP call: bad sizes are refused without touching a device
+    assert L.lib.msc_linear_fwd(None, None, None, None, None, None, 1, 1, 8, 0, 0, None) == -1
+    assert L.lib.msc_conv2d_fwd(1, 1, 1, None, 1, 8, 8, 3, 8, 3, 3, 1, 1, 1, None) == -1      # Cin=3 not a power of two >= 8
+
+
+def test_product_fails_loudly_without_extension(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import multimodal_sc_amd.lib as L\n"
+            "L.LIB_PATH = %r\n"
+            "L.lib._dll = None\n"
+            "try:\n    L.lib.load()\nexcept RuntimeError as e:\n    print('LOUD', 'no CPU/eager fallback' in str(e))\n") % (ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.check_output([sys.executable, "-c", code]).decode()
+    assert "LOUD True" in out
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "multimodal_sc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+# ------------------------------------------------------------------ oracle known answers
+def test_philox_known_answer_vectors():
+    from oracle.philox import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in kat:
+        r = philox4x32_10(*[[c] for c in ctr], *key)
+        assert tuple(int(x[0]) for x in r) == exp
+
+
+def test_oracle_channel_known_answers():
+    from oracle.model import Channel, power_normalize, psnr, select_action
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16, 256, generator=g) * 3
+    s = power_normalize(x)
+    assert (s.pow(2).mean(1) - 1).abs().max() < 1e-6
+    n = torch.randn(16, 256, generator=g)
+    snr = torch.full((16,), 10.0)
+    y = Channel("awgn")(x, snr, n)
+    assert torch.allclose(y - s, 10 ** (-0.5) * n, atol=1e-6)
+    h = torch.randn(16, 256, generator=g)
+    yr = Channel("rayleigh")(x, snr, n, h)
+    hc = torch.complex(h[:, 0::2], h[:, 1::2]) / math.sqrt(2)
+    nc = torch.complex(n[:, 0::2], n[:, 1::2]) * 10 ** (-0.5)
+    sc = torch.complex(s[:, 0::2], s[:, 1::2])
+    ref = sc + nc / hc
+    got = torch.complex(yr[:, 0::2], yr[:, 1::2])
+    assert ((got - ref).abs() / (1 + ref.abs())).max() < 1e-4
+    # PSNR: uniform error eps -> 20 log10(1/eps)
+    img = torch.rand(2, 3, 32, 32, generator=g)
+    assert (psnr(img + 0.05, img) - 20 * math.log10(1 / 0.05)).abs().max() < 1e-3
+    # arg-max ties -> lowest index
+    assert select_action(torch.tensor([[1.0, 3.0, 3.0], [2.0, 2.0, 2.0]])).tolist() == [1, 0]
+
+
+def test_oracle_ppo_hand_computed():
+    from oracle.model import MSCConfig, ppo_loss
+    cfg = MSCConfig(n_actions=3, c_entropy=0.0)
+    lp = -math.log(3.0)
+    logits = torch.zeros(4, 3)
+    value = torch.tensor([1.0, 0.0, -1.0, 2.0])
+    old = torch.tensor([lp, lp - math.log(1.5), lp + math.log(2.0), lp])
+    adv = torch.tensor([1.0, 2.0, -1.0, -3.0])
+    tot, pl, vl, ent = ppo_loss(logits, value, torch.zeros(4, dtype=torch.long), old, adv, torch.zeros(4), cfg)
+    assert abs(float(pl) - 0.1) < 1e-6 and abs(float(vl) - 0.75) < 1e-6 and abs(float(ent) - math.log(3)) < 1e-6
+
+
+def test_oracle_resnet18_shape_and_param_count():
+    from oracle.model import ImageEncoder
+    enc = ImageEncoder()
+    n = sum(p.numel() for p in enc.parameters())
+    assert n == 11176512          # torchvision resnet18 minus the 512x1000 fc (+bias): 11,689,512 - 513,000
+    assert enc(torch.zeros(2, 3, 64, 64)).shape == (2, 512, 2, 2)
+
+
+def test_state_dict_round_trip_shapes():
+    """product param specs cover exactly the oracle's state_dict (after the documented OHWI / head packing)."""
+    from multimodal_sc_amd.model import named_config, param_specs
+    from oracle.model import build_oracle, named_config as onc
+    for name in ("C0", "C3"):
+        specs = {k: s for k, s, _ in param_specs(named_config(name))}
+        sd = build_oracle(onc(name)).state_dict()
+        sd = {k: v for k, v in sd.items() if "running_" not in k and "num_batches" not in k}
+        ok = set(sd) - {"head.policy.weight", "head.policy.bias", "head.value.weight", "head.value.bias"}
+        pk = set(specs) - {"head.out.weight", "head.out.bias"}
+        assert ok == pk, (ok ^ pk)
+        for k in ok:
+            v = sd[k]
+            if v.dim() == 4:
+                exp = (v.shape[0], v.shape[2], v.shape[3], 8 if k == "image_encoder.conv1.weight" else v.shape[1])
+            else:
+                exp = tuple(v.shape)
+            assert specs[k] == exp, (k, specs[k], exp)

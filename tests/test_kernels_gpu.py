@@ -1,0 +1,484 @@
+"""Per-kernel parity: every HIP op (through the C-ABI) against plain PyTorch-CPU fp32 on the same seeded inputs.
+
+Tolerances (stated here, used below):
+  f32 mode : |gpu - ref| <= 2e-4 * max(1, max|ref|)   (exact-fp32 MFMA; only the summation order differs)
+  bf16 mode: the reference is computed in fp32 FROM THE bf16-ROUNDED INPUTS, so the only differences are the
+             bf16 rounding of the stored output (2^-8 relative) and summation order: 1.2e-2 * max(1, max|ref|);
+             fp32 outputs of bf16 kernels (weight gradients, statistics) use 2e-3 (inputs identical, fp32 accumulate;
+             the slack covers bf16-rounded intermediate activations inside fused chains).
+Integer outputs (arg-max, pool indices) are compared bit-exactly.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ["f32", "bf16"]
+
+
+def tol(dtype, fp32_out=False):
+    if dtype == "f32":
+        return 2e-4
+    return 2e-3 if fp32_out else 1.2e-2
+
+
+def check(name, got, ref, t):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= t * scale, f"{name}: max err {err:.3e} > {t:.1e} * {scale:.3e}"
+
+
+@pytest.fixture(scope="module")
+def rts(cuda):
+    from multimodal_sc_amd.runtime import Runtime
+    return {d: Runtime(d, "cuda:0") for d in DTYPES}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """value as the kernel sees it (bf16-rounded in bf16 mode), as fp32 CPU"""
+    return t.to(torch.bfloat16).float() if dtype == "bf16" else t.clone()
+
+
+def dev(t, rt):
+    return t.to(rt.device).to(rt.tdtype).contiguous()
+
+
+class FakeParam:
+    """ParamRef stand-in built from CPU tensors for single-op tests."""
+
+    def __init__(self, rt, w, kind):
+        from multimodal_sc_amd import lib as L
+        self.shape = tuple(w.shape)
+        self.kind = kind
+        self.p = w.to(rt.device).float().contiguous()
+        self.c = self.p if rt.dt == L.MSC_F32 else self.p.to(rt.tdtype)
+        self.g = torch.full_like(self.p, float("nan"))
+        self.t = None
+        if kind == "conv":
+            co, kh, kw, ci = w.shape
+            self.t = torch.empty(w.numel(), dtype=rt.tdtype, device=rt.device)
+            rt.call("msc_permute3_cast", self.p, self.t, co, kh * kw, ci, rt.dt)
+        elif kind == "linear":
+            n, k = w.shape
+            self.t = torch.empty(w.numel(), dtype=rt.tdtype, device=rt.device)
+            rt.call("msc_permute3_cast", self.p, self.t, n, 1, k, rt.dt)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / linear
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,act", [(128, 128, 64, 0), (300, 200, 96, 1), (64, 16, 256, 3), (1000, 512, 512, 2), (37, 3072, 64, 4), (50, 64, 8, 0)])
+def test_linear_fwd_bwd(rts, dtype, M, N, K, act):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
+    dy = rnd(M, N, seed=4)
+    xq, wq = q(x, dtype).requires_grad_(), q(w, dtype).requires_grad_()
+    bq = b.clone().requires_grad_()
+    pre = xq @ wq.t() + bq
+    ref = [pre, torch.relu(pre), TF.gelu(pre), torch.tanh(pre), torch.sigmoid(pre)][act]
+    W, Bp = FakeParam(rt, w, "linear"), FakeParam(rt, b, "vec")
+    xd = dev(x, rt).requires_grad_()
+    y = F.Linear.apply(xd, None, rt, W, Bp, act, True)
+    check("y", y, ref, tol(dtype))
+    # backward: feed the same upstream gradient; the reference activation-gradient uses its own (fp32) output
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    check("dx", xd.grad, xq.grad, tol(dtype) * 2)
+    check("dw", W.g, wq.grad, tol(dtype, True) * 4)
+    check("db", Bp.g, bq.grad, tol(dtype, True) * 4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_residual(rts, dtype):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    M, N, K = 200, 128, 64
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=5)
+    W, Bp = FakeParam(rt, w, "linear"), FakeParam(rt, b, "vec")
+    y, _ = F.linear_fwd(rt, dev(x, rt), W, Bp, 0, res=dev(r, rt))
+    check("y", y, q(x, dtype) @ q(w, dtype).t() + b + q(r, dtype), tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_layouts(rts, dtype):
+    """all four operand-layout combinations of the general kernel, with strides and a ragged K (306)"""
+    rt = rts[dtype]
+    Bz, M, N, K = 6, 70, 64, 306
+    Kp = 320
+    A = rnd(Bz, M, Kp, seed=1)
+    A[..., K:] = 0
+    Bm = rnd(Bz, N, Kp, seed=2)
+    Bm[..., K:] = 0
+    ref = torch.einsum("zmk,znk->zmn", q(A, dtype), q(Bm, dtype)) * 0.5
+    for a_k in (1, 0):
+        for b_k in (1, 0):
+            Ad = dev(A if a_k else A[..., :K].transpose(1, 2).contiguous(), rt)     # [z][M][Kp] or [z][K][M]
+            Bd = dev(Bm if b_k else Bm[..., :K].transpose(1, 2).contiguous(), rt)
+            if not a_k:  # pad M to a multiple of 8 for the mn-major leading dimension
+                Ad = dev(torch.nn.functional.pad(A[..., :K].transpose(1, 2), (0, 2)), rt)  # [z][K][72]
+            lda = Kp if a_k else Ad.shape[-1]
+            ldb = Kp if b_k else N
+            C = torch.full((Bz, M, N), float("nan"), dtype=torch.float32, device=rt.device)
+            rt.call("msc_gemm_batched", Ad, Bd, C, M, N, K, lda, ldb, N, a_k, b_k, Bz, 2, 2 * Ad.shape[1] * Ad.shape[2],
+                    Ad.shape[1] * Ad.shape[2], 2 * Bd.shape[1] * Bd.shape[2], Bd.shape[1] * Bd.shape[2], 2 * M * N, M * N, 0.5, 1, rt.dt)
+            check(f"C a_k={a_k} b_k={b_k}", C, ref, tol(dtype, True))
+
+
+# ------------------------------------------------------------------------------------------------ conv + BN
+CONV_CASES = [  # B,H,W,Cin,Cout,K,stride,pad
+    (2, 16, 16, 8, 64, 7, 2, 3),
+    (2, 14, 14, 64, 64, 3, 1, 1),
+    (2, 14, 14, 64, 128, 3, 2, 1),
+    (2, 14, 14, 64, 128, 1, 2, 0),
+    (3, 7, 7, 256, 512, 3, 1, 1),
+    (4, 32, 32, 64, 64, 3, 1, 1),
+    (8, 1, 1, 512, 512, 3, 1, 1),
+    (8, 2, 2, 256, 512, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv_bn_fwd_bwd(rts, dtype, case, relu):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    B, H, W, Cin, Cout, K, s, p = case
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, K, K, Cin, seed=2, scale=1 / math.sqrt(K * K * Cin))
+    gamma, beta = 1 + 0.1 * rnd(Cout, seed=3), 0.1 * rnd(Cout, seed=4)
+    xq, wq = q(x, dtype).requires_grad_(), q(w, dtype).requires_grad_()
+    gq, bq = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    conv = TF.conv2d(xq.permute(0, 3, 1, 2), wq.permute(0, 3, 1, 2), None, s, p)
+    bn = TF.batch_norm(conv, None, None, gq, bq, True, 0.0, 1e-5)
+    ref = (torch.relu(bn) if relu else bn).permute(0, 2, 3, 1)
+    Wp, G, Bt = FakeParam(rt, w, "conv"), FakeParam(rt, gamma, "vec"), FakeParam(rt, beta, "vec")
+    xd = dev(x, rt).requires_grad_()
+    y = F.ConvBNAct.apply(xd, None, rt, Wp, G, Bt, s, p, relu, True)
+    # BN divides by the batch std: a 1x1 output map with batch 8 amplifies rounding; scale tolerance accordingly
+    amp = 4.0 if B * y.shape[1] * y.shape[2] < 64 else 1.0
+    check("y", y, ref, tol(dtype) * amp)
+    dy = rnd(*ref.shape, seed=5)
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    check("dx", xd.grad, xq.grad, tol(dtype) * 4 * amp)
+    check("dw", Wp.g, wq.grad, tol(dtype, True) * 8 * amp)
+    check("dgamma", G.g, gq.grad, tol(dtype, True) * 8 * amp)
+    check("dbeta", Bt.g, bq.grad, tol(dtype, True) * 8 * amp)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride", [1, 2])
+def test_basic_block(rts, dtype, stride):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    B, H, Cin = 4, 12, 64
+    Cout = 64 if stride == 1 else 128
+    x = rnd(B, H, H, Cin, seed=1)
+    ws = {"conv1": rnd(Cout, 3, 3, Cin, seed=2, scale=0.05), "conv2": rnd(Cout, 3, 3, Cout, seed=3, scale=0.05)}
+    if stride == 2:
+        ws["dconv"] = rnd(Cout, 1, 1, Cin, seed=4, scale=0.1)
+    vec = {k: (1 + 0.1 * rnd(Cout, seed=10 + i)) if k.endswith("g") else 0.1 * rnd(Cout, seed=20 + i)
+           for i, k in enumerate(["bn1g", "bn1b", "bn2g", "bn2b", "dbng", "dbnb"])}
+    xq = q(x, dtype).requires_grad_()
+    tw = {k: q(v, dtype).requires_grad_() for k, v in ws.items()}
+    tv = {k: v.clone().requires_grad_() for k, v in vec.items()}
+
+    def cbn(inp, wk, gk, bk, s, pad):
+        c = TF.conv2d(inp, tw[wk].permute(0, 3, 1, 2), None, s, pad)
+        return TF.batch_norm(c, None, None, tv[gk], tv[bk], True, 0.0, 1e-5)
+
+    xin = xq.permute(0, 3, 1, 2)
+    o = torch.relu(cbn(xin, "conv1", "bn1g", "bn1b", stride, 1))
+    o = cbn(o, "conv2", "bn2g", "bn2b", 1, 1)
+    idt = cbn(xin, "dconv", "dbng", "dbnb", stride, 0) if stride == 2 else xin
+    ref = torch.relu(o + idt).permute(0, 2, 3, 1)
+    p = {k: FakeParam(rt, v, "conv") for k, v in ws.items()}
+    p.update({k: FakeParam(rt, v, "vec") for k, v in vec.items() if stride == 2 or not k.startswith("db")})
+    xd = dev(x, rt).requires_grad_()
+    y = F.BasicBlockFn.apply(xd, rt, p, stride)
+    check("y", y, ref, tol(dtype) * 2)
+    dy = rnd(*ref.shape, seed=7)
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    check("dx", xd.grad, xq.grad, tol(dtype) * 8)
+    for k in ws:
+        check("d" + k, p[k].g, tw[k].grad, tol(dtype, True) * 16)
+    for k in p:
+        if k in vec:
+            check("d" + k, p[k].g, tv[k].grad, tol(dtype, True) * 16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_maxpool(rts, dtype):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    x = rnd(2, 17, 17, 64, seed=1)
+    xq = q(x, dtype).requires_grad_()
+    ref = TF.max_pool2d(xq.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    xd = dev(x, rt).requires_grad_()
+    y = F.MaxPool.apply(xd, rt, 3, 2, 1)
+    check("y", y, ref, 0.0)
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    check("dx", xd.grad, xq.grad, tol(dtype))
+
+
+# ------------------------------------------------------------------------------------------------ LN / tokens / pools
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm(rts, dtype):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    x, g, b = rnd(3, 50, 512, seed=1) * 2 + 0.5, 1 + 0.1 * rnd(512, seed=2), 0.1 * rnd(512, seed=3)
+    xq, gq, bq = q(x, dtype).requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = TF.layer_norm(xq, (512,), gq, bq, 1e-5)
+    G, Bp = FakeParam(rt, g, "vec"), FakeParam(rt, b, "vec")
+    xd = dev(x, rt).requires_grad_()
+    y = F.LayerNorm.apply(xd, rt, G, Bp)
+    check("y", y, ref, tol(dtype))
+    dy = rnd(3, 50, 512, seed=4)
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    check("dx", xd.grad, xq.grad, tol(dtype) * 2)
+    check("dg", G.g, gq.grad, tol(dtype, True) * 4)
+    check("db", Bp.g, bq.grad, tol(dtype, True) * 4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tokens_meanpool(rts, dtype):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    B, D = 3, 512
+    s0, s1, s2, pos = rnd(B, 4, D, seed=1), rnd(B, 9, D, seed=2), rnd(B, 1, D, seed=3), rnd(14, D, seed=4)
+    t = [q(s, dtype).requires_grad_() for s in (s0, s1, s2)]
+    pq = pos.clone().requires_grad_()
+    tok = torch.cat(t, 1) + pq
+    ref = tok.mean(1)
+    Pp = FakeParam(rt, pos, "vec")
+    d = [dev(s, rt).requires_grad_() for s in (s0, s1, s2)]
+    tk = F.TokensAssemble.apply(d[0], d[1], d[2], rt, Pp)
+    check("tokens", tk, tok, tol(dtype))
+    y = F.MeanPool.apply(tk, rt)
+    check("mean", y, ref, tol(dtype))
+    dy = rnd(B, D, seed=5)
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    for i in range(3):
+        check(f"ds{i}", d[i].grad, t[i].grad, tol(dtype))
+    check("dpos", Pp.g, pq.grad, tol(dtype, True) * 2)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [306, 49, 1])
+def test_attention(rts, dtype, T):
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    B, h, hd = 2, 8, 64
+    D = h * hd
+    qkv = rnd(B * T, 3 * D, seed=1)
+    do = rnd(B * T, D, seed=2)
+    t = q(qkv, dtype).requires_grad_()
+    v5 = t.view(B, T, 3, h, hd)
+    qq, kk, vv = (v5[:, :, i].transpose(1, 2) for i in range(3))
+    att = torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(hd), -1)
+    ref = (att @ vv).transpose(1, 2).reshape(B * T, D)
+    qd = dev(qkv, rt)
+    o, P = F.attention_fwd(rt, qd, B, T, h, hd)
+    check("o", o, ref, tol(dtype))
+    ref.backward(q(do, dtype))
+    dqkv = F.attention_bwd(rt, dev(do, rt), qd, P, B, T, h, hd)
+    check("dqkv", dqkv, t.grad, tol(dtype) * 4)
+
+
+# ------------------------------------------------------------------------------------------------ channel
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["awgn", "rayleigh"])
+def test_channel(rts, dtype, mode):
+    import sys
+    from multimodal_sc_amd import functional as F, lib as L
+    from oracle.model import Channel
+    rt = rts[dtype]
+    B, k = 10, 256
+    x, n, hfad = rnd(B, k, seed=1) * 3, rnd(B, k, seed=2), rnd(B, k, seed=3)
+    snr = torch.linspace(-5, 15, B)
+    xq = q(x, dtype).requires_grad_()
+    ref = Channel(mode)(xq, snr, n, hfad)
+    xd = dev(x, rt).requires_grad_()
+    y = F.ChannelFn.apply(xd, rt, snr.to(rt.device), n.to(rt.device), hfad.to(rt.device), L.CH_AWGN if mode == "awgn" else L.CH_RAYLEIGH, 0)
+    # Rayleigh deep fades amplify noise by 1/|h|^2: compare relative to the output magnitude
+    check("y", y, ref, tol(dtype))
+    dy = rnd(B, k, seed=4)
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    check("dx", xd.grad, xq.grad, tol(dtype) * 2)
+
+
+def test_channel_power_and_snr(rts):
+    """known-answer checks: unit power after normalisation; measured SNR within 0.1 dB (Philox noise)."""
+    from multimodal_sc_amd import lib as L
+    rt = rts["f32"]
+    B, k = 4096, 256
+    x = (rnd(B, k, seed=1) * 5).to(rt.device)
+    for snr_db in (-5.0, 0.0, 10.0):
+        snr = torch.full((B,), snr_db, device=rt.device)
+        y, scale = rt.f32(B, k), rt.f32(B)
+        rt.call("msc_channel_fwd", x, None, None, snr, y, scale, B, k, L.CH_AWGN, 1234, rt.dt)
+        s = x * scale[:, None]
+        assert abs(float(s.pow(2).mean()) - 1.0) < 1e-5
+        meas = 10 * math.log10(1.0 / float((y - s).pow(2).mean()))
+        assert abs(meas - snr_db) < 0.1, (meas, snr_db)
+    # Rayleigh: E|h|^2 = 1 from the fading stream
+    z = rt.f32(1 << 20)
+    rt.call("msc_philox_normal", z, (1 << 20) // 4, 77, 1)
+    h2 = (z.view(-1, 2) / math.sqrt(2)).pow(2).sum(-1).mean()
+    assert abs(float(h2) - 1.0) < 1e-2
+
+
+def test_philox_matches_cpu_restatement(rts):
+    from oracle.philox import philox_normal
+    rt = rts["f32"]
+    nq = 1000
+    z = rt.f32(nq * 4)
+    rt.call("msc_philox_normal", z, nq, 0x123456789ABCDEF, 1)
+    ref = torch.from_numpy(philox_normal(nq, 0x123456789ABCDEF, 1))
+    check("philox", z, ref, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ pillars
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pillar(rts, dtype):
+    from multimodal_sc_amd import functional as F
+    from oracle.model import BEVEncoder, MSCConfig
+    rt = rts[dtype]
+    cfg = MSCConfig(bev_grid=32, bev_range=12.8)
+    B, Np = 2, 4096
+    g = torch.Generator().manual_seed(0)
+    pts = torch.cat([(torch.rand(B, Np, 2, generator=g) * 2 - 1) * 14.0, torch.rand(B, Np, 2, generator=g)], -1)  # some outside
+    enc = BEVEncoder(cfg)
+    ref = enc.pillar_grid(pts)
+    dy = rnd(*ref.shape, seed=3)
+    ref.backward(q(dy, dtype))
+    W, Bp = FakeParam(rt, enc.point_mlp.weight.detach(), "vec"), FakeParam(rt, enc.point_mlp.bias.detach(), "vec")
+    anchor = torch.zeros(1, device=rt.device, requires_grad=True)
+    out = F.PillarFn.apply(pts.to(rt.device), anchor, rt, W, Bp, cfg.bev_grid, cfg.bev_range)
+    check("grid", out, ref, tol(dtype))
+    out.backward(dev(dy, rt))
+    check("dw", W.g, enc.point_mlp.weight.grad, tol(dtype, True) * 4)
+    check("db", Bp.g, enc.point_mlp.bias.grad, tol(dtype, True) * 4)
+
+
+# ------------------------------------------------------------------------------------------------ heads / losses
+def test_argmax_ties_bit_exact(rts):
+    for dtype in DTYPES:
+        rt = rts[dtype]
+        x = torch.tensor([[1.0, 3.0, 3.0, 2.0], [5.0, 5.0, 5.0, 5.0], [-1.0, -2.0, -1.0, -3.0], [0.0, 0.0, 1.0, 1.0]])
+        x = torch.nn.functional.pad(x, (0, 12), value=9.0)   # padded columns must be ignored (n=4, ld=16)
+        big = rnd(1000, 16, seed=1)
+        allx = torch.cat([x, big.to(torch.bfloat16).float()], 0)
+        out = torch.empty(allx.shape[0], dtype=torch.int64, device=rt.device)
+        rt.call("msc_argmax_rows", dev(allx, rt), out, allx.shape[0], 4, 16, rt.dt)
+        assert torch.equal(out.cpu(), torch.argmax(allx[:, :4], -1))
+        assert out[:4].tolist() == [1, 0, 0, 2]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ppo_loss(rts, dtype):
+    from oracle.model import MSCConfig, ppo_loss
+    rt = rts[dtype]
+    cfg = MSCConfig()
+    B, A = 64, 9
+    head = rnd(B, 16, seed=1)
+    g = torch.Generator().manual_seed(2)
+    act = torch.randint(0, A, (B,), generator=g)
+    old = -math.log(A) + 0.3 * torch.randn(B, generator=g)
+    adv, ret = torch.randn(B, generator=g), torch.randn(B, generator=g)
+    hq = q(head, dtype).requires_grad_()
+    tot, pl, vl, ent = ppo_loss(hq[:, :A], hq[:, A], act, old, adv, ret, cfg)
+    tot.backward()
+    terms = rt.f32(4)
+    hd_ = dev(head, rt)
+    dh = torch.empty_like(hd_)
+    rt.call("msc_ppo_loss", hd_, act.to(rt.device), old.to(rt.device), adv.to(rt.device), ret.to(rt.device), terms, dh, B, A, 16,
+            cfg.clip_eps, cfg.c_value, cfg.c_entropy, rt.dt)
+    check("terms", terms, torch.stack([tot, pl, vl, ent]), 1e-5)
+    check("dhead", dh, hq.grad, 1e-5 if dtype == "f32" else 1e-2 * float(hq.grad.abs().max()))
+
+
+def test_ppo_hand_computed(rts):
+    """4-sample hand-computed clipped surrogate: uniform logits -> ratio known in closed form."""
+    rt = rts["f32"]
+    A, B = 3, 4
+    head = torch.zeros(B, 16)
+    head[:, A] = torch.tensor([1.0, 0.0, -1.0, 2.0])
+    lp = -math.log(3.0)
+    old = torch.tensor([lp, lp - math.log(1.5), lp + math.log(2.0), lp])     # ratios 1, 1.5, 0.5, 1
+    adv = torch.tensor([1.0, 2.0, -1.0, -3.0])
+    ret = torch.tensor([0.0, 0.0, 0.0, 0.0])
+    # surr = min(r*A, clip(r,.8,1.2)*A): 1, min(3,2.4)=2.4, min(-.5,-.8)=-.8, -3  -> policy = -mean = 0.1
+    terms, dh = rt.f32(4), torch.empty(B, 16, device=rt.device)
+    rt.call("msc_ppo_loss", head.to(rt.device), torch.zeros(B, dtype=torch.int64, device=rt.device), old.to(rt.device), adv.to(rt.device),
+            ret.to(rt.device), terms, dh, B, A, 16, 0.2, 0.5, 0.0, rt.dt)
+    t = terms.cpu()
+    assert abs(float(t[1]) - 0.1) < 1e-6
+    assert abs(float(t[2]) - 0.5 * (1 + 0 + 1 + 4) / 4) < 1e-6
+    assert abs(float(t[3]) - math.log(3.0)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_recon_loss_psnr(rts, dtype):
+    rt = rts[dtype]
+    B, G, P = 3, 2, 32
+    img = torch.rand(B, 3, G * P, G * P, generator=torch.Generator().manual_seed(1))
+    pat = torch.rand(B * G * G, P * P * 3, generator=torch.Generator().manual_seed(2))
+    pq = q(pat, dtype)
+    rec = pq.view(B, G, G, P, P, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, G * P, G * P)
+    sse_ref = (rec - img).pow(2).flatten(1).sum(1)
+    sse, ws = rt.f32(B), rt.f32(B * 32)
+    pd = dev(pat, rt)
+    dp = torch.empty_like(pd)
+    rt.call("msc_recon_loss", pd, img.to(rt.device), sse, dp, ws, B, G, P, 0.25, rt.dt)
+    check("sse", sse, sse_ref, 1e-5)
+    out_img = rt.f32(B, 3, G * P, G * P)
+    rt.call("msc_unpatchify", pd, out_img, B, G, P, rt.dt)
+    check("unpatchify", out_img, rec, 0.0)
+    dref = 0.25 * (rec - img).view(B, 3, G, P, G, P).permute(0, 2, 4, 3, 5, 1).reshape(B * G * G, P * P * 3)
+    check("drecon", dp, dref, tol(dtype))
+    # PSNR known answers: uniform error eps -> 20 log10(1/eps)
+    eps = 0.1
+    pat2 = (img + eps).view(B, 3, G, P, G, P).permute(0, 2, 4, 3, 5, 1).reshape(B * G * G, P * P * 3)
+    rt2 = rts["f32"]
+    sse2 = rt2.f32(B)
+    rt2.call("msc_recon_loss", pat2.to(rt2.device), img.to(rt2.device), sse2, None, rt2.f32(B * 32), B, G, P, 0.0, rt2.dt)
+    psnr = 10 * torch.log10(3 * (G * P) ** 2 / sse2.cpu())
+    assert (psnr - 20 * math.log10(1 / eps)).abs().max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_adam_matches_torch(rts):
+    rt = rts["bf16"]
+    n = 10000
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, seed=2), rnd(n, seed=3)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    p, m, v = p0.to(rt.device), torch.zeros(n, device=rt.device), torch.zeros(n, device=rt.device)
+    sh = torch.empty(n, dtype=torch.bfloat16, device=rt.device)
+    for step, g in enumerate((g1, g2), 1):
+        ref.grad = g.clone()
+        opt.step()
+        rt.call("msc_adam_step", p, (g * 4).to(rt.device), m, v, sh, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, step, 0.25, rt.dt)
+    check("p", p, ref, 1e-6)
+    assert torch.equal(sh.cpu(), p.cpu().to(torch.bfloat16))
