@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the multimodal semantic-communication training step on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one forward + backward + gradient all-reduce + fused-Adam update over a batch of 64 synthetic frames PER
+GPU (weak scaling) of the workload BASELINE.json's metric is quoted on: camera 3x224x224 + 16384-point LiDAR cloud +
+ego state, cross-modal fusion transformer, semantic codec over AWGN at 10 dB, PPO policy/value head (config "C3";
+C1/C2 selectable).  bf16 storage / bf16 MFMA with fp32 accumulation.  Inputs are resident in HBM before timing.
+Rank 0 prints ONE JSON line with the contract fields plus:
+  roofline     — the MFMA contraction kernel (gemm_kernel: implicit-GEMM convs, linears, attention GEMMs): algorithmic
+                 FLOPs per step / summed duration of its launches per step, measured with HIP events on the launch
+                 stream in an instrumented step, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline — the build-authored PyTorch-CPU oracle timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def gemm_flops(name, s):
+    """algorithmic FLOPs of one C-ABI GEMM-family call from its scalar arguments (see Runtime.call)."""
+    def conv(B, H, W, Cin, Cout, KH, KW, st, p):
+        Ho, Wo = (H + 2 * p - KH) // st + 1, (W + 2 * p - KW) // st + 1
+        cin = 3 if Cin == 8 else Cin           # the RGB stem is zero-padded to 8 channels; count the real 3
+        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin
+    if name in ("msc_conv2d_fwd", "msc_conv2d_dgrad"):
+        return conv(*s[:9])
+    if name == "msc_conv2d_wgrad":
+        return conv(*s[1:10])
+    if name in ("msc_linear_fwd", "msc_linear_dgrad"):
+        return 2.0 * s[0] * s[1] * s[2]
+    if name == "msc_linear_wgrad":
+        return 2.0 * s[1] * s[2] * s[3]
+    if name == "msc_gemm_batched":
+        return 2.0 * s[0] * s[1] * s[2] * s[8]
+    return None
+
+
+def cpu_baseline(cfg_name, seconds_budget=20.0):
+    """oracle fwd+bwd (fp32, all host threads) on a bounded sample of the same workload -> frames/s"""
+    import torch
+    from oracle import model as O
+    cfg = O.named_config(cfg_name)
+    B = 4
+    m = O.build_oracle(cfg, seed=0)
+    batch = O.synthetic_batch(cfg, B, seed=0)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        out = m(batch["image"], batch.get("points"), batch.get("state"), batch["snr_db"], batch["noise"], batch["fading"])
+        loss, _ = O.total_loss(out, batch["image"], cfg, batch["ppo"])
+        loss.backward()
+
+    step()  # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 6):
+        step()
+        n += 1
+    dt = time.time() - t0
+    return {"value": B * n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/model.py fwd+bwd, config {cfg_name}, batch {B} x {n} steps, fp32, no optimizer step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from multimodal_sc_amd.trainer import Trainer
+    from oracle import model as O   # synthetic input generator only; never on the measured path
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    cfg = named_config(args.config)
+    model = MultimodalSC(cfg, dtype=args.dtype, device=dev, seed=0)
+    trainer = Trainer(model, lr=1e-4, use_ppo=True)
+    B = args.batch
+    cpu_batch = O.synthetic_batch(O.named_config(args.config), B, seed=1000 + rank)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in cpu_batch.items() if k != "ppo"}
+    batch["ppo"] = {k: v.to(dev) for k, v in cpu_batch["ppo"].items()}
+    batch["noise"] = None      # throughput mode: in-kernel Philox noise
+    batch["fading"] = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        terms = trainer.step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    met = model.metrics(terms)
+
+    result = {
+        "metric": "multimodal frames/sec (whole job) at batch 64 per GPU, training step fwd+bwd+allreduce+Adam",
+        "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.config}: camera 3x{cfg.img_size}x{cfg.img_size}"
+                               + (f" + {cfg.n_points}-pt LiDAR BEV" if cfg.use_lidar else "") + (" + ego-state" if cfg.use_state else "")
+                               + f", fusion transformer T={cfg.n_tokens} d={cfg.d_model} L={cfg.n_layers}, {cfg.channel.upper()} 10 dB, PPO head",
+                   "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+        "frames_per_s_per_gpu": B * args.steps / dt, "psnr_db": met["psnr"], "loss": met["loss"],
+    }
+
+    if rank == 0 and not args.no_roofline:
+        rt = model.rt
+        rt.profile = []
+        trainer.forward_backward(batch)          # no collective here: only rank 0 runs the instrumented pass
+        model.params.adam_step(lr=1e-4)
+        torch.cuda.synchronize()
+        by = {}
+        gemm_t = gemm_f = 0.0
+        n_gemm = 0
+        for name, s, e0, e1 in rt.profile:
+            ms = e0.elapsed_time(e1)
+            d = by.setdefault(name, [0, 0.0])
+            d[0] += 1
+            d[1] += ms
+            f = gemm_flops(name, s)
+            if f is not None:
+                gemm_t += ms
+                gemm_f += f
+                n_gemm += 1
+        rt.profile = None
+        achieved = gemm_f / (gemm_t * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_kernel<bf16,*>",
+                              "launches_per_step": n_gemm, "algorithmic_gflop_per_step": gemm_f / 1e9, "kernel_ms_per_step": gemm_t}
+        result["breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.config)
+        result["gpu_over_cpu"] = result["frames_per_s_per_gpu"] / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,14 +80,15 @@ int msc_gemm_batched(const void* A, const void* Bm, void* C, int M, int N, int K
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm (training-mode batch statistics, per-GPU under DP) and LayerNorm.
- * msc_bn_finalize: mean/rstd [C] from the conv epilogue partials (fp64 combine, fixed order).
- * msc_bn_apply   : y = relu?(gamma*(x-mean)*rstd + beta + res?)            x,y,res: T [rows][C]
+ * msc_bn_finalize: mean/rstd [C] from the conv epilogue partials (fp64 combine, fixed order) and the folded
+ *                  per-channel affine scale = gamma*rstd, shift = beta - mean*scale used by msc_bn_apply.
+ * msc_bn_apply   : y = relu?(x*scale + shift + res?)                         x,y,res: T [rows][C]
  * msc_bn_bwd     : dz = dy*(y>0 if relu); dx (T); dres = dz (optional, T); dgamma/dbeta fp32
  *                  ws >= msc_bn_bwd_workspace_bytes(C). */
-int msc_bn_finalize(const float* partial, int nblk, int C, int64_t count, float eps, float* mean, float* rstd,
-                    void* stream);
-int msc_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                 const void* res, void* y, int64_t rows, int C, int relu, int dtype, void* stream);
+int msc_bn_finalize(const float* partial, int nblk, int C, int64_t count, float eps, const float* gamma,
+                    const float* beta, float* mean, float* rstd, float* scale, float* shift, void* stream);
+int msc_bn_apply(const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t rows,
+                 int C, int relu, int dtype, void* stream);
 int64_t msc_bn_bwd_workspace_bytes(int C);
 int msc_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, int64_t rows,

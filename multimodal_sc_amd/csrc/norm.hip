@@ -1,35 +1,76 @@
-// norm.hip — BatchNorm (training statistics, NHWC) and LayerNorm, forward and backward.
-// All HBM-bound: 16-byte vector accesses, fp32 statistics, fixed-order (bitwise reproducible)
-// two-stage column reductions (per-block partials -> finalize), no float atomics.
-// Roles: ImageEncoder / BEV conv stack (BN), FusionTransformer (LN).  Build-authored; the upstream
-// reference has no code (SURVEY.md finding zero).
+// norm.hip — BatchNorm (training statistics, NHWC) and LayerNorm, forward and backward, plus the column-sum used
+// for bias / positional-embedding gradients.
+// All HBM-bound: 16-byte vector accesses, fp32 statistics, fixed-order (bitwise reproducible) two-stage column
+// reductions (per-block partials -> parallel finalize), no float atomics.
+// Roles: ImageEncoder / BEV conv stack (BN), FusionTransformer (LN).  Build-authored; the upstream reference has no
+// code (SURVEY.md finding zero).
 #include "msc_common.h"
 
 #define BN_MAX_BLOCKS 1024
 
-// ---------------------------------------------------------------- BN finalize (after conv epilogue)
-// partial: [nblk][2][C] fp32 column sums / sums of squares.  fp64 combine: E[x^2]-E[x]^2 is formed
-// in double so the cancellation does not cost fp32 digits.
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double inv_count, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// ------------------------------------------------------------------------------------------------
+// Finalize of every two-stat column reduction: partial [nblk][2][C] -> sums over blocks.
+// block = 8 channels x 32 row-lanes; lane l sums blocks l, l+32, ... in fp64, then a fixed-order LDS tree.
+enum { FIN_BN_FWD = 0, FIN_SUMS = 1 };
+struct FinArgs {
+  const float* partial; int nblk; int C;
+  // FIN_BN_FWD
+  double inv_count; float eps; const float* gamma; const float* beta; float* mean; float* rstd; float* scale; float* shift;
+  // FIN_SUMS
+  float* out0; float* out1; float* acc0; float* acc1; int accumulate;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void finalize2_kernel(const FinArgs a) {
+  __shared__ double red[2][32][8];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += (double)partial[(long)b * 2 * C + c];
-    s2 += (double)partial[(long)b * 2 * C + C + c];
+  if (c < a.C) {
+    for (int b = rl; b < a.nblk; b += 32) {
+      s1 += (double)a.partial[(long)b * 2 * a.C + c];
+      s2 += (double)a.partial[(long)b * 2 * a.C + a.C + c];
+    }
   }
-  const double m = s1 * inv_count;
-  double var = s2 * inv_count - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
-  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl != 0 || c >= a.C) return;
+  s1 = 0.0; s2 = 0.0;
+  for (int r = 0; r < 32; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
+  if constexpr (MODE == FIN_BN_FWD) {
+    // E[x^2]-E[x]^2 formed in double so the cancellation does not cost fp32 digits
+    const double m = s1 * a.inv_count;
+    double var = s2 * a.inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float mu = (float)m;
+    a.mean[c] = mu;
+    a.rstd[c] = rs;
+    const float sc = a.gamma[c] * rs;
+    a.scale[c] = sc;
+    a.shift[c] = a.beta[c] - mu * sc;
+  } else {
+    const float f1 = (float)s1, f2 = (float)s2;
+    if (a.out0) a.out0[c] = f1;
+    if (a.out1) a.out1[c] = f2;
+    if (a.acc0) a.acc0[c] = (a.accumulate ? a.acc0[c] : 0.f) + f1;
+    if (a.acc1) a.acc1[c] = (a.accumulate ? a.acc1[c] : 0.f) + f2;
+  }
 }
 
-// y = relu?( gamma*(x-mean)*rstd + beta + res? )
+// load VEC consecutive per-channel floats
+template <int VEC> __device__ __forceinline__ void ldc(const float* __restrict__ p, float (&o)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p + j);
+    o[j] = t.x; o[j + 1] = t.y; o[j + 2] = t.z; o[j + 3] = t.w;
+  }
+}
+
+// y = relu?( x*scale[c] + shift[c] + res? )
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                 const T* __restrict__ res, T* __restrict__ y, long nvec, int C, int relu) {
   constexpr int VEC = msc_traits<T>::VEC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
@@ -38,10 +79,12 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     vecf<T> vx, vr;
     vx.load(x + e);
     if (res) vr.load(res + e);
+    float sc[VEC], sh[VEC];
+    ldc<VEC>(scale + c0, sc);
+    ldc<VEC>(shift + c0, sh);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const int c = c0 + j;
-      float v = (vx.v[j] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+      float v = fmaf(vx.v[j], sc[j], sh[j]);
       if (res) v += vr.v[j];
       if (relu) v = v > 0.f ? v : 0.f;
       vx.v[j] = v;
@@ -64,8 +107,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
   float s1[VEC], s2[VEC], mu[VEC], rs[VEC];
+  ldc<VEC>(mean + tx * VEC, mu);
+  ldc<VEC>(rstd + tx * VEC, rs);
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[tx * VEC + j]; rs[j] = rstd[tx * VEC + j]; }
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   if (ty < nty) {
     for (long r = r0 + ty; r < r1; r += nty) {
       const long e = r * C + tx * VEC;
@@ -82,7 +127,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       }
     }
   }
-  __shared__ float red[2][256 * 8 / 8 * 8];  // [stat][ty][C] with nty*C <= 256*VEC <= 2048
+  __shared__ float red[2][2048];  // [stat][ty][C] with nty*C <= 256*VEC <= 2048
   float* r1p = &red[0][0];
   float* r2p = &red[1][0];
   if (ty < nty) {
@@ -96,20 +141,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     partial[(long)blockIdx.x * 2 * C + c] = a;
     partial[(long)blockIdx.x * 2 * C + C + c] = b;
   }
-}
-
-// Stage 2: column-sum the partials in fixed order; out0 = sum of first stat, out1 = second.
-__global__ void colsum2_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out0,
-                                        float* __restrict__ out1, float* __restrict__ acc0, float* __restrict__ acc1,
-                                        int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) { a += partial[(long)k * 2 * C + c]; b += partial[(long)k * 2 * C + C + c]; }
-  out0[c] = a;
-  out1[c] = b;
-  if (acc0) acc0[c] = (accumulate ? acc0[c] : 0.f) + a;
-  if (acc1) acc1[c] = (accumulate ? acc1[c] : 0.f) + b;
 }
 
 // Stage 3: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M); dres = dz (optional)
@@ -127,13 +158,18 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     vd.load(dy + e);
     vx.load(x + e);
     if (relu) vy.load(y + e);
+    float mu[VEC], rs[VEC], ga[VEC], sa[VEC], sb[VEC];
+    ldc<VEC>(mean + c0, mu);
+    ldc<VEC>(rstd + c0, rs);
+    ldc<VEC>(gamma + c0, ga);
+    ldc<VEC>(sum_dz + c0, sa);
+    ldc<VEC>(sum_dzx + c0, sb);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const int c = c0 + j;
       float dz = vd.v[j];
       if (relu && !(vy.v[j] > 0.f)) dz = 0.f;
-      const float xh = (vx.v[j] - mean[c]) * rstd[c];
-      vo.v[j] = gamma[c] * rstd[c] * (dz - sum_dz[c] * inv_rows - xh * sum_dzx[c] * inv_rows);
+      const float xh = (vx.v[j] - mu[j]) * rs[j];
+      vo.v[j] = ga[j] * rs[j] * (dz - sa[j] * inv_rows - xh * sb[j] * inv_rows);
       vd.v[j] = dz;
     }
     vo.store(dx + e);
@@ -142,99 +178,112 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
 }
 
 // ---------------------------------------------------------------- LayerNorm
-// one wave per row; D % (64*VEC) == 0
+// one wave per row, the row lives in registers (D <= 64*LN_MAXC); D % (64*VEC) == 0
+#define LN_MAXC 16
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows,
                                                      int D, float eps) {
   constexpr int VEC = msc_traits<T>::VEC;
+  constexpr int MAXIT = LN_MAXC / VEC;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nit = D / (64 * VEC);
+  vecf<T> v[MAXIT];
   float s = 0.f;
-  for (int it = 0; it < nit; ++it) {
-    vecf<T> v;
-    v.load(x + row * D + (it * 64 + lane) * VEC);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) s += v.v[j];
-  }
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      v[it].load(x + row * D + (it * 64 + lane) * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s += v[it].v[j];
+    }
   const float mu = wave_sum(s) / (float)D;
   float q = 0.f;
-  for (int it = 0; it < nit; ++it) {
-    vecf<T> v;
-    v.load(x + row * D + (it * 64 + lane) * VEC);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { const float d = v.v[j] - mu; q += d * d; }
-  }
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { const float d = v[it].v[j] - mu; q += d * d; }
+    }
   const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-  for (int it = 0; it < nit; ++it) {
-    const int c0 = (it * 64 + lane) * VEC;
-    vecf<T> v;
-    v.load(x + row * D + c0);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) v.v[j] = (v.v[j] - mu) * rs * gamma[c0 + j] + beta[c0 + j];
-    v.store(y + row * D + c0);
-  }
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      const int c0 = (it * 64 + lane) * VEC;
+      float g[VEC], b[VEC];
+      ldc<VEC>(gamma + c0, g);
+      ldc<VEC>(beta + c0, b);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[it].v[j] = (v[it].v[j] - mu) * rs * g[j] + b[j];
+      v[it].store(y + row * D + c0);
+    }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// block = 4 waves, handles LN_ROWS_PER_BLOCK rows; each lane owns D/64 columns (<= 16 with D <= 1024)
-#define LN_ROWS_PER_BLOCK 32
+// block = 4 waves, LN_ROWS_PER_BLOCK rows (each wave takes every 4th); each lane owns D/64 columns
+#define LN_ROWS_PER_BLOCK 16
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ dadd,
                                                      T* __restrict__ dx, float* __restrict__ partial, long rows, int D) {
   constexpr int VEC = msc_traits<T>::VEC;
-  constexpr int MAXC = 16;
-  constexpr int MAXIT = MAXC / VEC;
+  constexpr int MAXIT = LN_MAXC / VEC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nit = D / (64 * VEC);
-  float dg[MAXC], db[MAXC];
+  float dg[LN_MAXC], db[LN_MAXC], ga[LN_MAXC];
 #pragma unroll
-  for (int j = 0; j < MAXC; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  for (int it = 0; it < MAXIT; ++it) {
+    float g[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) g[j] = 0.f;
+    if (it < nit) ldc<VEC>(gamma + (it * 64 + lane) * VEC, g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { dg[it * VEC + j] = 0.f; db[it * VEC + j] = 0.f; ga[it * VEC + j] = g[j]; }
+  }
   const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
   for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 4) {
     const long row = r0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
+    vecf<T> vd[MAXIT], vx[MAXIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it)
       if (it < nit) {
         const int c0 = (it * 64 + lane) * VEC;
-        vecf<T> vd, vx;
-        vd.load(dy + row * D + c0);
-        vx.load(x + row * D + c0);
+        vd[it].load(dy + row * D + c0);
+        vx[it].load(x + row * D + c0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const float xh = (vx.v[j] - mu) * rs;
-          const float g = vd.v[j] * gamma[c0 + j];
+          const float xh = (vx[it].v[j] - mu) * rs;
+          const float g = vd[it].v[j] * ga[it * VEC + j];
+          vx[it].v[j] = xh;
           s1 += g;
           s2 += g * xh;
-          dg[it * VEC + j] += vd.v[j] * xh;
-          db[it * VEC + j] += vd.v[j];
+          dg[it * VEC + j] += vd[it].v[j] * xh;
+          db[it * VEC + j] += vd[it].v[j];
         }
       }
-    }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
-    for (int it = 0; it < nit; ++it) {
-      const int c0 = (it * 64 + lane) * VEC;
-      vecf<T> vd, vx, va;
-      vd.load(dy + row * D + c0);
-      vx.load(x + row * D + c0);
-      if (dadd) va.load(dadd + row * D + c0);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float xh = (vx.v[j] - mu) * rs;
-        vx.v[j] = rs * (vd.v[j] * gamma[c0 + j] - s1 - xh * s2);
-        if (dadd) vx.v[j] += va.v[j];
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int c0 = (it * 64 + lane) * VEC;
+        vecf<T> va;
+        if (dadd) va.load(dadd + row * D + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float o = rs * (vd[it].v[j] * ga[it * VEC + j] - s1 - vx[it].v[j] * s2);
+          if (dadd) o += va.v[j];
+          vx[it].v[j] = o;
+        }
+        vx[it].store(dx + row * D + c0);
       }
-      vx.store(dx + row * D + c0);
-    }
   }
   // cross-wave reduce of dgamma/dbeta, then one partial row per block
   __shared__ float red[2][4][1024];
@@ -256,54 +305,98 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 }
 
 // ---------------------------------------------------------------- generic column sum (bias grads, dpos)
-// out[c] (+)= sum_r x[r][c];  stage 1 partials [nblk][C], stage 2 fixed-order sum
+// out[c] (+)= sum_r x[r][c];  stage 1: block = (cx column-chunks) x (256/cx row lanes) over a slab of rows
+#define COLSUM_MAX_BLOCKS 256
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
-                                                             long rows, long C, int rows_per_block) {
-  const long c = (long)blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+                                                             long rows, long C, int rows_per_block, int cx) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int nty = 256 / cx;
+  const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+  const long c0 = ((long)blockIdx.x * cx + tx) * VEC;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  for (long r = r0; r < r1; ++r) s += msc_traits<T>::ld(x + r * C + c);
-  partial[(long)blockIdx.y * C + c] = s;
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  if (c0 < C && ty < nty) {
+    for (long r = r0 + ty; r < r1; r += nty) {
+      vecf<T> v;
+      v.load(x + r * C + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += v.v[j];
+    }
+  }
+  __shared__ float red[2048];   // [ty][cx*VEC]
+  const int W = cx * VEC;
+  if (ty < nty) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[ty * W + tx * VEC + j] = s[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < W; c += 256) {
+    const long cg = (long)blockIdx.x * W + c;
+    if (cg >= C) break;
+    float a = 0.f;
+    for (int t = 0; t < nty; ++t) a += red[t * W + c];
+    partial[(long)blockIdx.y * C + cg] = a;
+  }
 }
 __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, long C, float* __restrict__ out,
                                        int accumulate) {
-  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = accumulate ? out[c] : 0.f;
-  for (int k = 0; k < nblk; ++k) s += partial[(long)k * C + c];
-  out[c] = s;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;     // 32 columns x 8 row lanes
+  const long c = (long)blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (c < C)
+    for (int k = rl; k < nblk; k += 8) s += partial[(long)k * C + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t = accumulate ? out[c] : 0.f;
+    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    out[c] = t;
+  }
 }
 
 static inline int ew_blocks(long n) {
   long b = (n + 255) / 256;
-  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
-extern "C" int msc_bn_finalize(const float* partial, int nblk, int C, int64_t count, float eps, float* mean,
-                               float* rstd, void* stream) {
-  MSC_CHECK_ARG(partial && mean && rstd && nblk > 0 && C > 0 && count > 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial, nblk, C,
-                     1.0 / (double)count, eps, mean, rstd);
+// ================================================================ C-ABI
+extern "C" int msc_bn_finalize(const float* partial, int nblk, int C, int64_t count, float eps, const float* gamma,
+                               const float* beta, float* mean, float* rstd, float* scale, float* shift, void* stream) {
+  MSC_CHECK_ARG(partial && gamma && beta && mean && rstd && scale && shift && nblk > 0 && C > 0 && count > 0);
+  FinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.partial = partial; a.nblk = nblk; a.C = C; a.inv_count = 1.0 / (double)count; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd; a.scale = scale; a.shift = shift;
+  hipLaunchKernelGGL(finalize2_kernel<FIN_BN_FWD>, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, a);
   return msc_launch_status();
 }
 
-extern "C" int msc_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
-                            const float* beta, const void* res, void* y, int64_t rows, int C, int relu, int dtype,
-                            void* stream) {
-  MSC_CHECK_ARG(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0);
+static void launch_fin_sums(const float* partial, int nblk, int C, float* out0, float* out1, float* acc0, float* acc1,
+                            int accumulate, hipStream_t st) {
+  FinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.partial = partial; a.nblk = nblk; a.C = C; a.out0 = out0; a.out1 = out1; a.acc0 = acc0; a.acc1 = acc1; a.accumulate = accumulate;
+  hipLaunchKernelGGL(finalize2_kernel<FIN_SUMS>, dim3(cdiv(C, 8)), dim3(256), 0, st, a);
+}
+
+extern "C" int msc_bn_apply(const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t rows,
+                            int C, int relu, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && scale && shift && y && rows > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSC_F32) {
     MSC_CHECK_ARG(C % 4 == 0);
     const long nvec = rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const float*)x, mean, rstd,
-                       gamma, beta, (const float*)res, (float*)y, nvec, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const float*)x, scale, shift,
+                       (const float*)res, (float*)y, nvec, C, relu);
   } else if (dtype == MSC_BF16) {
     MSC_CHECK_ARG(C % 8 == 0);
     const long nvec = rows * C / 8;
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const bf16_t*)x, mean,
-                       rstd, gamma, beta, (const bf16_t*)res, (bf16_t*)y, nvec, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const bf16_t*)x, scale, shift,
+                       (const bf16_t*)res, (bf16_t*)y, nvec, C, relu);
   } else
     return MSC_ERR_BAD_ARG;
   return msc_launch_status();
@@ -316,10 +409,10 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* m
                     const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, int64_t rows,
                     int C, int relu, int accumulate, hipStream_t st) {
   constexpr int VEC = msc_traits<T>::VEC;
-  if (C % VEC || C / VEC > 256 || C > 2048 / 1) return MSC_ERR_BAD_ARG;
+  if (C % VEC || C / VEC > 256) return MSC_ERR_BAD_ARG;
   const int ncx = C / VEC, nty = 256 / ncx;
   if (nty < 1 || (long)nty * C > 2048) return MSC_ERR_BAD_ARG;
-  int nblk = cdiv(rows, 256);
+  int nblk = cdiv(rows, 128);
   if (nblk > BN_MAX_BLOCKS) nblk = BN_MAX_BLOCKS;
   const int rpb = cdiv(rows, nblk);
   nblk = cdiv(rows, rpb);
@@ -327,8 +420,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* m
   float* sums = ws + (long)BN_MAX_BLOCKS * 2 * C;  // [2][C]
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y,
                      mean, rstd, partial, (long)rows, C, relu, rpb);
-  hipLaunchKernelGGL(colsum2_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, partial, nblk, C, sums, sums + C,
-                     dbeta, dgamma, accumulate);
+  launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
   const long nvec = rows * C / VEC;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dy, (const T*)x,
                      (const T*)y, mean, rstd, gamma, sums, sums + C, (T*)dx, (T*)dres, nvec, C, relu,
@@ -349,7 +441,7 @@ extern "C" int msc_bn_bwd(const void* dy, const void* x, const void* y, const fl
 
 extern "C" int msc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                  float* rstd, int64_t rows, int D, float eps, int dtype, void* stream) {
-  MSC_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0);
+  MSC_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0 && D <= 1024);
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)cdiv(rows, 4);
   if (dtype == MSC_F32) {
@@ -386,32 +478,34 @@ extern "C" int msc_layernorm_bwd(const void* dy, const void* x, const float* mea
   } else
     return MSC_ERR_BAD_ARG;
   // ws holds [nblk][2][D]: first stat = dgamma, second = dbeta
-  float* scratch = nullptr;
-  (void)scratch;
-  hipLaunchKernelGGL(colsum2_finalize_kernel, dim3(cdiv(D, 128)), dim3(128), 0, st, ws, nblk, D, ws, ws + D, dgamma,
-                     dbeta, accumulate);
+  launch_fin_sums(ws, nblk, D, nullptr, nullptr, dgamma, dbeta, accumulate, st);
   return msc_launch_status();
 }
 
-#define COLSUM_MAX_BLOCKS 256
 extern "C" int64_t msc_colsum_workspace_bytes(int64_t cols) { return (int64_t)COLSUM_MAX_BLOCKS * cols * 4; }
 
 // out[c] (+)= sum_r x[r][c]  (x is T [rows][cols]) — bias gradients, positional-embedding gradient
 extern "C" int msc_colsum(const void* x, float* out, float* ws, int64_t rows, int64_t cols, int accumulate, int dtype,
                           void* stream) {
   MSC_CHECK_ARG(x && out && ws && rows > 0 && cols > 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   hipStream_t st = (hipStream_t)stream;
-  int nblk = cdiv(rows, 64);
+  const int VEC = dtype == MSC_F32 ? 4 : 8;
+  MSC_CHECK_ARG(cols % VEC == 0);
+  // cx = column chunks per block: a power of two <= 256 covering the row (or 256)
+  int cx = 1;
+  while (cx < 256 && (long)cx * VEC < cols) cx <<= 1;
+  const int nty = 256 / cx;
+  int nblk = cdiv(rows, (long)nty * 8);
   if (nblk > COLSUM_MAX_BLOCKS) nblk = COLSUM_MAX_BLOCKS;
+  if (nblk < 1) nblk = 1;
   const int rpb = cdiv(rows, nblk);
   nblk = cdiv(rows, rpb);
-  dim3 grid((unsigned)cdiv(cols, 256), (unsigned)nblk);
+  dim3 grid((unsigned)cdiv(cols, (long)cx * VEC), (unsigned)nblk);
   if (dtype == MSC_F32)
-    hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ws, (long)rows, (long)cols, rpb);
-  else if (dtype == MSC_BF16)
-    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ws, (long)rows, (long)cols, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ws, (long)rows, (long)cols, rpb, cx);
   else
-    return MSC_ERR_BAD_ARG;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, ws, nblk, (long)cols, out, accumulate);
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ws, (long)rows, (long)cols, rpb, cx);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, st, ws, nblk, (long)cols, out, accumulate);
   return msc_launch_status();
 }

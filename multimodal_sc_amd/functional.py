@@ -33,10 +33,11 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
     y_raw = rt.empty(B, Ho, Wo, Cout)
     partial = rt.workspace("bn_partial", nblk * 2 * Cout * 4)
     rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.dt)
-    mean, rstd = rt.f32(Cout), rt.f32(Cout)
-    rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, mean, rstd)
+    stats = rt.f32(4, Cout)                      # mean, rstd (kept for backward), scale, shift (folded affine)
+    mean, rstd = stats[0], stats[1]
+    rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, gamma.p, beta.p, mean, rstd, stats[2], stats[3])
     y = rt.empty(B, Ho, Wo, Cout)
-    rt.call("msc_bn_apply", y_raw, mean, rstd, gamma.p, beta.p, res, y, M, Cout, int(relu), rt.dt)
+    rt.call("msc_bn_apply", y_raw, stats[2], stats[3], res, y, M, Cout, int(relu), rt.dt)
     return y, y_raw, mean, rstd
 
 

@@ -37,7 +37,8 @@ class Runtime:
         self.device = torch.device(device)
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
-        L.lib.load()                 # fail loudly, now, if the HIP extension is missing
+        self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
+        L.lib.load()                # fail loudly, now, if the HIP extension is missing
 
     @property
     def stream(self):
@@ -59,7 +60,15 @@ class Runtime:
         return t
 
     def call(self, name, *args):
-        return L.call(name, *args, self.stream)
+        if self.profile is None:
+            return L.call(name, *args, self.stream)
+        # instrumented pass (bench.py): HIP events on the launch stream around every C-ABI call
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = L.call(name, *args, self.stream)
+        e1.record()
+        self.profile.append((name, tuple(a for a in args if not hasattr(a, "data_ptr") and a is not None), e0, e1))
+        return rc
 
 
 class ParamStore:

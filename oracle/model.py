@@ -87,8 +87,31 @@ def named_config(name: str) -> MSCConfig:
     raise ValueError(name)
 
 
+# ---- optional emulation of the product's bf16 storage points (tests only) ---------------------------------------
+# The HIP path stores every activation tensor in bf16 (fp32 accumulation inside each kernel).  With _ROUND set, the
+# oracle rounds (straight-through) at the same storage points, so a bf16 run can be compared against "fp32 math with
+# the same roundings" instead of against pure fp32 — deep BN/ReLU stacks amplify rounding noise, and this separates
+# that inherent sensitivity from implementation error.  Default: None = pure fp32 oracle.
+_ROUND = None
+
+
+def _r(t):
+    return t if _ROUND is None else _ROUND(t)
+
+
+class emulate_bf16_storage:
+    def __enter__(self):
+        global _ROUND
+        _ROUND = lambda t: t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+        return self
+
+    def __exit__(self, *a):
+        global _ROUND
+        _ROUND = None
+
+
 def _bn(x, w, b):
-    return F.batch_norm(x, None, None, w, b, True, 0.0, 1e-5)
+    return F.batch_norm(_r(x), None, None, w, b, True, 0.0, 1e-5)
 
 
 class BasicBlock(nn.Module):
@@ -104,11 +127,11 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x
-        out = F.relu(_bn(self.conv1(x), self.bn1.weight, self.bn1.bias))
+        out = _r(F.relu(_bn(self.conv1(x), self.bn1.weight, self.bn1.bias)))
         out = _bn(self.conv2(out), self.bn2.weight, self.bn2.bias)
         if self.downsample is not None:
-            idt = _bn(self.downsample[0](x), self.downsample[1].weight, self.downsample[1].bias)
-        return F.relu(out + idt)
+            idt = _r(_bn(self.downsample[0](x), self.downsample[1].weight, self.downsample[1].bias))
+        return _r(F.relu(out + idt))
 
 
 class ImageEncoder(nn.Module):
@@ -124,7 +147,7 @@ class ImageEncoder(nn.Module):
             setattr(self, f"layer{i}", nn.Sequential(BasicBlock(chans[i - 1], chans[i], stride), BasicBlock(chans[i], chans[i], 1)))
 
     def forward(self, img):
-        x = F.relu(_bn(self.conv1(img), self.bn1.weight, self.bn1.bias))
+        x = _r(F.relu(_bn(self.conv1(_r(img)), self.bn1.weight, self.bn1.bias)))
         x = F.max_pool2d(x, 3, 2, 1)
         for i in range(1, 5):
             x = getattr(self, f"layer{i}")(x)
@@ -152,8 +175,9 @@ class BEVEncoder(nn.Module):
         cell = torch.tensor(2.0 * cfg.bev_range / G, dtype=torch.float32)
         lo = torch.tensor(-cfg.bev_range, dtype=torch.float32)
         feat = F.relu(self.point_mlp(points))                        # [B,N,C]
-        fx = torch.floor((points[..., 0] - lo) / cell)
-        fy = torch.floor((points[..., 1] - lo) / cell)
+        pf = points.float()                                          # cell assignment is defined in fp32 arithmetic
+        fx = torch.floor((pf[..., 0] - lo) / cell)
+        fy = torch.floor((pf[..., 1] - lo) / cell)
         valid = (fx >= 0) & (fx < G) & (fy >= 0) & (fy < G)
         idx = (fy.clamp(0, G - 1) * G + fx.clamp(0, G - 1)).long()   # [B,N]
         feat = feat * valid.unsqueeze(-1)                            # invalid points contribute 0 (= empty)
@@ -162,10 +186,10 @@ class BEVEncoder(nn.Module):
         return grid.view(B, G, G, cfg.point_feat)
 
     def forward(self, points):
-        g = self.pillar_grid(points).permute(0, 3, 1, 2)             # NCHW for torch convs
-        x = F.relu(_bn(self.conv1(g), self.bn1.weight, self.bn1.bias))
-        x = F.relu(_bn(self.conv2(x), self.bn2.weight, self.bn2.bias))
-        x = F.relu(_bn(self.conv3(x), self.bn3.weight, self.bn3.bias))
+        g = _r(self.pillar_grid(points)).permute(0, 3, 1, 2)         # NCHW for torch convs
+        x = _r(F.relu(_bn(self.conv1(g), self.bn1.weight, self.bn1.bias)))
+        x = _r(F.relu(_bn(self.conv2(x), self.bn2.weight, self.bn2.bias)))
+        x = _r(F.relu(_bn(self.conv3(x), self.bn3.weight, self.bn3.bias)))
         return x  # [B,512,G/8,G/8]
 
 
@@ -176,7 +200,7 @@ class StateEncoder(nn.Module):
         self.fc2 = nn.Linear(cfg.d_model, cfg.d_model)
 
     def forward(self, s):
-        return self.fc2(F.relu(self.fc1(s)))
+        return _r(self.fc2(_r(F.relu(self.fc1(_r(s))))))
 
 
 class Attention(nn.Module):
@@ -188,10 +212,10 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, T, D = x.shape
-        qkv = self.qkv(x).view(B, T, 3, self.h, D // self.h)
+        qkv = _r(self.qkv(x)).view(B, T, 3, self.h, D // self.h)
         q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
-        att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D // self.h), dim=-1)
-        o = (att @ v).transpose(1, 2).reshape(B, T, D)
+        att = _r(torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D // self.h), dim=-1))
+        o = _r((att @ v).transpose(1, 2).reshape(B, T, D))
         return self.proj(o)
 
 
@@ -202,7 +226,7 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(f, d)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return self.fc2(_r(F.gelu(_r(self.fc1(x)))))
 
 
 class FusionLayer(nn.Module):
@@ -214,8 +238,8 @@ class FusionLayer(nn.Module):
         self.mlp = MLP(d, f)
 
     def forward(self, x):
-        x = x + self.attn(self.ln1(x))
-        return x + self.mlp(self.ln2(x))
+        x = _r(x + self.attn(_r(self.ln1(x))))
+        return _r(x + self.mlp(_r(self.ln2(x))))
 
 
 class FusionTransformer(nn.Module):
@@ -227,10 +251,10 @@ class FusionTransformer(nn.Module):
         self.ln_f = nn.LayerNorm(cfg.d_model)
 
     def forward(self, tokens):
-        x = tokens + self.pos_embed
+        x = _r(tokens + self.pos_embed)
         for l in self.layers:
             x = l(x)
-        return self.ln_f(x)
+        return _r(self.ln_f(x))
 
 
 class SemanticEncoder(nn.Module):
@@ -240,7 +264,7 @@ class SemanticEncoder(nn.Module):
         self.fc2 = nn.Linear(cfg.d_model, cfg.n_symbols)
 
     def forward(self, f):
-        return self.fc2(F.relu(self.fc1(f)))     # un-normalised symbols; Channel applies the power constraint
+        return _r(self.fc2(_r(F.relu(self.fc1(f)))))     # un-normalised symbols; Channel applies the power constraint
 
 
 def power_normalize(x):
@@ -279,7 +303,7 @@ class SemanticDecoder(nn.Module):
         self.fc2 = nn.Linear(cfg.d_model, cfg.d_model)
 
     def forward(self, y):
-        return self.fc2(F.relu(self.fc1(y)))
+        return _r(self.fc2(_r(F.relu(self.fc1(y)))))
 
 
 class PolicyValueHead(nn.Module):
@@ -290,8 +314,8 @@ class PolicyValueHead(nn.Module):
         self.value = nn.Linear(cfg.head_hidden, 1)
 
     def forward(self, z):
-        h = torch.tanh(self.fc(z))
-        return self.policy(h), self.value(h).squeeze(-1)
+        h = _r(torch.tanh(self.fc(z)))
+        return _r(self.policy(h)), _r(self.value(h)).squeeze(-1)
 
 
 class ReconHead(nn.Module):
@@ -307,8 +331,8 @@ class ReconHead(nn.Module):
     def forward(self, z):
         cfg = self.cfg
         B, g, P = z.shape[0], cfg.recon_grid, cfg.patch
-        h = F.relu(self.fc1(z)).view(B * g * g, cfg.recon_hidden)
-        p = torch.sigmoid(self.fc2(h)).view(B, g, g, P, P, 3)              # (gy,gx,py,px,c)
+        h = _r(F.relu(self.fc1(z))).view(B * g * g, cfg.recon_hidden)
+        p = _r(torch.sigmoid(self.fc2(h))).view(B, g, g, P, P, 3)          # (gy,gx,py,px,c)
         return p.permute(0, 5, 1, 3, 2, 4).reshape(B, 3, g * P, g * P)      # NCHW
 
 
@@ -337,9 +361,9 @@ class MultimodalSC(nn.Module):
         if cfg.use_state:
             toks.append(self.state_encoder(state).unsqueeze(1))
         x = self.fusion(torch.cat(toks, 1))
-        f = x.mean(1)
+        f = _r(x.mean(1))
         sym = self.semantic_encoder(f)
-        y = self.channel(sym, snr_db, noise, fading)
+        y = _r(self.channel(sym, snr_db, noise, fading))
         z = self.semantic_decoder(y)
         logits, value = self.head(z)
         recon = self.recon(z)

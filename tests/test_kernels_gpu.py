@@ -35,6 +35,19 @@ def check(name, got, ref, t):
     assert err <= t * scale, f"{name}: max err {err:.3e} > {t:.1e} * {scale:.3e}"
 
 
+def check_grad(name, got, ref, t, dtype, relu):
+    """Gradients behind a ReLU in bf16 mode: an activation within bf16 rounding of 0 can land on the other side of the
+    mask than in the fp32 reference, which moves a few isolated entries by O(|dy|) — a max-abs bound is the wrong
+    yardstick for that.  Those cases use the relative Frobenius error (<= 4e-2); everything else uses max-abs."""
+    if dtype == "bf16" and relu:
+        g, r = got.detach().double().cpu(), ref.detach().double().cpu()
+        assert g.shape == r.shape and torch.isfinite(g).all(), name
+        rel = ((g - r).norm() / r.norm().clamp_min(1e-30)).item()
+        assert rel <= 4e-2, f"{name}: relative Frobenius error {rel:.3e} > 4e-2"
+    else:
+        check(name, got, ref, t)
+
+
 @pytest.fixture(scope="module")
 def rts(cuda):
     from multimodal_sc_amd.runtime import Runtime
@@ -49,6 +62,12 @@ def rnd(*shape, seed=0, scale=1.0):
 def q(t, dtype):
     """value as the kernel sees it (bf16-rounded in bf16 mode), as fp32 CPU"""
     return t.to(torch.bfloat16).float() if dtype == "bf16" else t.clone()
+
+
+def ste(t, dtype):
+    """bf16 mode: round to bf16 at the points where the kernels store bf16 activations (straight-through for the
+    gradient), so that ReLU masks / BN inputs of the reference see exactly the stored values."""
+    return t if dtype == "f32" else t + (t.detach().to(torch.bfloat16).float() - t.detach())
 
 
 def dev(t, rt):
@@ -161,7 +180,7 @@ def test_conv_bn_fwd_bwd(rts, dtype, case, relu):
     gamma, beta = 1 + 0.1 * rnd(Cout, seed=3), 0.1 * rnd(Cout, seed=4)
     xq, wq = q(x, dtype).requires_grad_(), q(w, dtype).requires_grad_()
     gq, bq = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
-    conv = TF.conv2d(xq.permute(0, 3, 1, 2), wq.permute(0, 3, 1, 2), None, s, p)
+    conv = ste(TF.conv2d(xq.permute(0, 3, 1, 2), wq.permute(0, 3, 1, 2), None, s, p), dtype)
     bn = TF.batch_norm(conv, None, None, gq, bq, True, 0.0, 1e-5)
     ref = (torch.relu(bn) if relu else bn).permute(0, 2, 3, 1)
     Wp, G, Bt = FakeParam(rt, w, "conv"), FakeParam(rt, gamma, "vec"), FakeParam(rt, beta, "vec")
@@ -173,10 +192,10 @@ def test_conv_bn_fwd_bwd(rts, dtype, case, relu):
     dy = rnd(*ref.shape, seed=5)
     ref.backward(q(dy, dtype))
     y.backward(dev(dy, rt))
-    check("dx", xd.grad, xq.grad, tol(dtype) * 4 * amp)
-    check("dw", Wp.g, wq.grad, tol(dtype, True) * 8 * amp)
-    check("dgamma", G.g, gq.grad, tol(dtype, True) * 8 * amp)
-    check("dbeta", Bt.g, bq.grad, tol(dtype, True) * 8 * amp)
+    check_grad("dx", xd.grad, xq.grad, tol(dtype) * 4 * amp, dtype, relu)
+    check_grad("dw", Wp.g, wq.grad, tol(dtype, True) * 8 * amp, dtype, relu)
+    check_grad("dgamma", G.g, gq.grad, tol(dtype, True) * 8 * amp, dtype, relu)
+    check_grad("dbeta", Bt.g, bq.grad, tol(dtype, True) * 8 * amp, dtype, relu)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -197,13 +216,13 @@ def test_basic_block(rts, dtype, stride):
     tv = {k: v.clone().requires_grad_() for k, v in vec.items()}
 
     def cbn(inp, wk, gk, bk, s, pad):
-        c = TF.conv2d(inp, tw[wk].permute(0, 3, 1, 2), None, s, pad)
+        c = ste(TF.conv2d(inp, tw[wk].permute(0, 3, 1, 2), None, s, pad), dtype)
         return TF.batch_norm(c, None, None, tv[gk], tv[bk], True, 0.0, 1e-5)
 
     xin = xq.permute(0, 3, 1, 2)
-    o = torch.relu(cbn(xin, "conv1", "bn1g", "bn1b", stride, 1))
+    o = ste(torch.relu(cbn(xin, "conv1", "bn1g", "bn1b", stride, 1)), dtype)
     o = cbn(o, "conv2", "bn2g", "bn2b", 1, 1)
-    idt = cbn(xin, "dconv", "dbng", "dbnb", stride, 0) if stride == 2 else xin
+    idt = ste(cbn(xin, "dconv", "dbng", "dbnb", stride, 0), dtype) if stride == 2 else xin
     ref = torch.relu(o + idt).permute(0, 2, 3, 1)
     p = {k: FakeParam(rt, v, "conv") for k, v in ws.items()}
     p.update({k: FakeParam(rt, v, "vec") for k, v in vec.items() if stride == 2 or not k.startswith("db")})
@@ -213,12 +232,12 @@ def test_basic_block(rts, dtype, stride):
     dy = rnd(*ref.shape, seed=7)
     ref.backward(q(dy, dtype))
     y.backward(dev(dy, rt))
-    check("dx", xd.grad, xq.grad, tol(dtype) * 8)
+    check_grad("dx", xd.grad, xq.grad, tol(dtype) * 8, dtype, True)
     for k in ws:
-        check("d" + k, p[k].g, tw[k].grad, tol(dtype, True) * 16)
+        check_grad("d" + k, p[k].g, tw[k].grad, tol(dtype, True) * 16, dtype, True)
     for k in p:
         if k in vec:
-            check("d" + k, p[k].g, tv[k].grad, tol(dtype, True) * 16)
+            check_grad("d" + k, p[k].g, tv[k].grad, tol(dtype, True) * 16, dtype, True)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
