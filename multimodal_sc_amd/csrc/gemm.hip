@@ -1,22 +1,30 @@
 // gemm.hip — the one MFMA contraction kernel of the path, specialised by operand access mode:
 //   C[z][m][n] = epilogue( sum_k A(m,k) * B(n,k) )
 // Operand modes (template parameters, one per operand):
-//   OPM_DENSE_K     operand stored [row][k], k contiguous                    (linear fwd, QK^T ...)
-//   OPM_DENSE_MN    operand stored [k][row], row contiguous (transposed into LDS on the write)
+//   OPM_DENSE_K     operand stored [row][k], k contiguous                    (linear fwd/dgrad, QK^T ...)
+//   OPM_DENSE_MN    operand stored [k][row], row contiguous                  (weight gradients, P^T dO ...)
 //   OPM_CONV_FWD    A = NHWC activations gathered on the fly, rows=(b,ho,wo), k=(kh,kw,cin)
 //   OPM_CONV_DGRAD  A = NHWC output-gradients gathered, rows=(b,h,w), k=(kh,kw,cout)
 //   OPM_CONV_WGRAD  B = NHWC activations gathered, reduction k=(b,ho,wo), rows n=(kh,kw,cin)
 // so convolution is an implicit GEMM: there is no im2col buffer in HBM.
 //
-// Tile: 128 x BN (BN = 128 or 64) x 64 bytes of K per step; 256 threads = 4 waves in 2x2, each wave
-// owns (64 x BN/2) as 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, or the exact-fp32
-// v_mfma_f32_32x32x2_f32 in parity mode).  Global->register->LDS staging, two LDS buffers, the
-// global loads of tile t+1 are issued before the MFMAs of tile t and written after them (one barrier
-// per K step).  LDS rows are 64 B; 16-byte chunk c of row r lives at c ^ ((r>>2)&3), which makes the
-// ds_read_b128 fragment reads conflict-free (MI355X_MICROARCH.md §LDS, 16-lane groups).
+// Tile 128 x BN (BN = 128 | 64) x 64 bytes of K per step; 256 threads = 4 waves (2x2), each wave owns 64 x BN/2 as
+// 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16; exact-fp32 v_mfma_f32_32x32x2_f32 in parity mode).
 //
-// Build-authored: the upstream reference has no code (SURVEY.md finding zero); roles per
-// BASELINE.json: ImageEncoder/BEV conv stack, FusionTransformer, SemanticEncoder/Decoder, heads.
+// Staging (gfx950): operands go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, no
+// VGPR round trip).  The per-lane SOURCE offset does the gather (implicit-GEMM taps, transposition-free weight
+// gradients) and the XOR bank swizzle (the LDS image itself is lane-linear, as the hardware requires); lanes whose
+// element is padding / out of range use an out-of-range buffer offset, which the hardware turns into zeros in LDS.
+//   k-major operands : LDS rows of 64 B, chunk c of row r at c ^ ((r>>2)&3)      -> conflict-free ds_read_b128
+//   mn-major operands: LDS image [k][row] as it lies in HBM, chunk ^ swizzle(k)  -> ds_read_b64_tr_b16 (hardware
+//                      transpose) builds the MFMA fragment; no transposing pass anywhere (bf16).
+// Two LDS buffers: the DMA of K-step t+1 is in flight while the MFMAs of step t run; one barrier per K step.
+// The exact-fp32 parity mode has no transposed LDS read, so its mn-major operands are staged through registers and
+// transposed on the LDS write (correctness path, not tuned).
+// Workgroup ids are remapped so that the tiles sharing an activation row-block run on one XCD (shared L2).
+//
+// Build-authored: the upstream reference has no code (SURVEY.md finding zero); roles per BASELINE.json:
+// ImageEncoder/BEV conv stack, FusionTransformer, SemanticEncoder/Decoder, heads.
 #include "msc_common.h"
 
 enum { OPM_DENSE_K = 0, OPM_DENSE_MN = 1, OPM_CONV_FWD = 2, OPM_CONV_DGRAD = 3, OPM_CONV_WGRAD = 4 };
@@ -33,53 +41,87 @@ struct GemmParams {
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define DMA_OOB 0x80000000u   // >= num_records of every descriptor built here: the DMA writes zeros
 
 template <int MODE> struct mode_is_kmajor { static constexpr bool value = (MODE == OPM_DENSE_K || MODE == OPM_CONV_FWD || MODE == OPM_CONV_DGRAD); };
 
 __device__ __forceinline__ int lds_chunk_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// swizzle of the 16-byte chunk index inside an mn-major LDS row of ROWB bytes, keyed by the k row
+template <int ROWB> __device__ __forceinline__ int mn_swz(int krow) {
+  return ROWB == 256 ? ((krow & 3) << 2) : (((krow >> 1) & 1) << 2);
+}
 
 // ------------------------------------------------------------------------------------------------
-// Operand loader: global -> registers (16-byte chunks) -> LDS tile [ROWS][64 B] (k contiguous).
+// Operand loader.  DMA = true: LDS-DMA path (k-major any dtype; mn-major bf16).  DMA = false: registers + transposing
+// LDS write (mn-major fp32 only).
 template <typename T, int MODE, int ROWS> struct OperandLoader {
+  static constexpr bool KM = mode_is_kmajor<MODE>::value;
+  static constexpr bool DMA = KM || sizeof(T) == 2;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int KT = 64 / sizeof(T);
-  static constexpr int NCH = ROWS * 4 / 256;   // chunks per thread per K step
-  static constexpr int CPR = ROWS / VEC;        // chunks per reduction row (MN-major modes)
+  static constexpr int NCH = ROWS * 4 / 256;                   // 16-byte chunks per thread per K step
+  static constexpr int ROWB = KM ? 64 : ROWS * (int)sizeof(T); // LDS row bytes
+  static constexpr int CPR = ROWB / 16;                        // chunks per LDS row (DMA) / per reduction row (REG)
+  static constexpr int RPI = 1024 / ROWB;                      // LDS rows written by one DMA wave-instruction
 
-  const T* ptr[NCH];   // dense modes: running pointer
+  __amdgpu_buffer_rsrc_t rs;
+  const T* base;
+  long ld;
+  uint32_t off[NCH];   // dense modes: running byte offset
   int kk[NCH];         // current k (reduction index) of the chunk
   bool ok[NCH];        // row (k-major) or column (mn-major) inside the matrix
-  // conv state
   int a0[NCH], a1[NCH], a2[NCH];  // fwd/dgrad: hi0, wi0, kh ; wgrad: ho, wo, b
   int a3[NCH], a4[NCH];           // fwd/dgrad: kw, cin     ; wgrad: kh, kw
-  long boff[NCH];                 // batch base offset (fwd/dgrad) or cin (wgrad)
+  uint32_t boff[NCH];             // batch base (elements, fwd/dgrad) or cin (wgrad)
 
-  __device__ __forceinline__ void init(const GemmParams& p, const T* base, long ld, int rows_total,
-                                       int row0, int k0) {
-    const int tid = threadIdx.x;
+  // (row-in-tile, logical chunk) this thread moves for slot i
+  static __device__ __forceinline__ void slot(int i, int& r, int& c) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (DMA) {
+      const int j = wave * NCH + i;                 // DMA instruction index inside the tile
+      if constexpr (KM) {
+        r = 16 * j + (lane >> 2);
+        c = (lane & 3) ^ ((r >> 2) & 3);
+      } else {
+        r = RPI * j + lane / CPR;                   // k row inside the K step
+        c = (lane % CPR) ^ mn_swz<ROWB>(r);        // logical chunk along the mn axis
+      }
+    } else {
+      const int id = tid + i * 256;
+      r = id / CPR;
+      c = id % CPR;
+    }
+  }
+
+  __device__ __forceinline__ void init(const GemmParams& p, const T* b, long ldm, int rows_total, int row0, int k0) {
+    base = b;
+    ld = ldm;
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)0x7ffffff0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int id = tid + i * 256;
+      int r, c;
+      slot(i, r, c);
       if constexpr (MODE == OPM_DENSE_K) {
-        const int row = row0 + (id >> 2), c = id & 3;
+        const int row = row0 + r;
         ok[i] = row < rows_total;
         kk[i] = k0 + c * VEC;
-        ptr[i] = base + (long)(ok[i] ? row : 0) * ld + kk[i];
+        off[i] = (uint32_t)(((long)(ok[i] ? row : 0) * ld + kk[i]) * (long)sizeof(T));
       } else if constexpr (MODE == OPM_DENSE_MN) {
-        const int r = id / CPR, cc = id % CPR;
-        const int col = row0 + cc * VEC;
+        const int col = row0 + c * VEC;
         ok[i] = col < rows_total;
         kk[i] = k0 + r;
-        ptr[i] = base + (long)kk[i] * ld + (ok[i] ? col : 0);
+        off[i] = (uint32_t)(((long)kk[i] * ld + (ok[i] ? col : 0)) * (long)sizeof(T));
       } else if constexpr (MODE == OPM_CONV_FWD) {
-        const int row = row0 + (id >> 2), c = id & 3;
+        const int row = row0 + r;
         ok[i] = row < rows_total;
         const int rr = ok[i] ? row : 0;
         const int wo = rr % p.cWo, t = rr / p.cWo;
-        const int ho = t % p.cHo, b = t / p.cHo;
+        const int ho = t % p.cHo, bb = t / p.cHo;
         a0[i] = ho * p.cS - p.cP;
         a1[i] = wo * p.cS - p.cP;
-        boff[i] = (long)b * p.cH * p.cW * p.cC;
+        boff[i] = (uint32_t)bb * (uint32_t)(p.cH * p.cW * p.cC);
         const int k = k0 + c * VEC;
         const int tap = k >> p.cLogC;
         a4[i] = k & (p.cC - 1);
@@ -87,26 +129,25 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
         a3[i] = tap - a2[i] * p.cKW;
       } else if constexpr (MODE == OPM_CONV_DGRAD) {
         // rows are INPUT pixels (b,h,w) of size cH x cW; gathered tensor is dy [cB,cHo,cWo,cC]
-        const int row = row0 + (id >> 2), c = id & 3;
+        const int row = row0 + r;
         ok[i] = row < rows_total;
         const int rr = ok[i] ? row : 0;
         const int w = rr % p.cW, t = rr / p.cW;
-        const int h = t % p.cH, b = t / p.cH;
+        const int h = t % p.cH, bb = t / p.cH;
         a0[i] = h + p.cP;
         a1[i] = w + p.cP;
-        boff[i] = (long)b * p.cHo * p.cWo * p.cC;
+        boff[i] = (uint32_t)bb * (uint32_t)(p.cHo * p.cWo * p.cC);
         const int k = k0 + c * VEC;
         const int tap = k >> p.cLogC;
         a4[i] = k & (p.cC - 1);
         a2[i] = tap / p.cKW;
         a3[i] = tap - a2[i] * p.cKW;
       } else {  // OPM_CONV_WGRAD: columns n=(kh,kw,cin) fixed per thread, reduction over (b,ho,wo)
-        const int r = id / CPR, cc = id % CPR;
-        const int col = row0 + cc * VEC;
+        const int col = row0 + c * VEC;
         ok[i] = col < rows_total;
         const int cl = ok[i] ? col : 0;
         const int tap = cl >> p.cLogC;
-        boff[i] = cl & (p.cC - 1);
+        boff[i] = (uint32_t)(cl & (p.cC - 1));
         a3[i] = tap / p.cKW;
         a4[i] = tap - a3[i] * p.cKW;
         const int pix = k0 + r;
@@ -119,77 +160,91 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
     }
   }
 
-  // load the current K step into regs (zeros where out of range) and advance by one K step
-  __device__ __forceinline__ void load(const GemmParams& p, const T* base, long ld, int klimit, uint4 (&regs)[NCH]) {
+  // byte offset of slot i's chunk for the current K step (DMA_OOB where the element is padding), then advance
+  __device__ __forceinline__ uint32_t next_offset(const GemmParams& p, int klimit, int i) {
+    uint32_t v = DMA_OOB;
+    if constexpr (MODE == OPM_DENSE_K) {
+      if (ok[i] && kk[i] < klimit) v = off[i];
+      off[i] += 64;
+      kk[i] += KT;
+    } else if constexpr (MODE == OPM_DENSE_MN) {
+      if (ok[i] && kk[i] < klimit) v = off[i];
+      off[i] += (uint32_t)(KT * ld * (long)sizeof(T));
+      kk[i] += KT;
+    } else if constexpr (MODE == OPM_CONV_FWD) {
+      const int hi = a0[i] + a2[i], wi = a1[i] + a3[i];
+      if (ok[i] && a2[i] < p.cKH && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
+        v = (boff[i] + ((uint32_t)(hi * p.cW + wi) << p.cLogC) + (uint32_t)a4[i]) * (uint32_t)sizeof(T);
+      const int cin = a4[i] + KT;
+      a3[i] += cin >> p.cLogC;
+      a4[i] = cin & (p.cC - 1);
+      while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
+    } else if constexpr (MODE == OPM_CONV_DGRAD) {
+      const int th = a0[i] - a2[i], tw = a1[i] - a3[i];
+      const int sm = p.cS - 1;
+      const int ho = th >> p.cLogS, wo = tw >> p.cLogS;
+      if (ok[i] && a2[i] < p.cKH && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && ho < p.cHo && wo < p.cWo)
+        v = (boff[i] + ((uint32_t)(ho * p.cWo + wo) << p.cLogC) + (uint32_t)a4[i]) * (uint32_t)sizeof(T);
+      const int co = a4[i] + KT;
+      a3[i] += co >> p.cLogC;
+      a4[i] = co & (p.cC - 1);
+      while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
+    } else {
+      const int hi = a0[i] * p.cS - p.cP + a3[i], wi = a1[i] * p.cS - p.cP + a4[i];
+      if (ok[i] && kk[i] < klimit && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
+        v = ((((uint32_t)a2[i] * (uint32_t)p.cH + (uint32_t)hi) * (uint32_t)p.cW + (uint32_t)wi) << p.cLogC) * (uint32_t)sizeof(T) +
+            boff[i] * (uint32_t)sizeof(T);
+      kk[i] += KT;
+      a1[i] += KT;
+      while (a1[i] >= p.cWo) {
+        a1[i] -= p.cWo;
+        if (++a0[i] == p.cHo) { a0[i] = 0; ++a2[i]; }
+      }
+    }
+    return v;
+  }
+
+  // DMA path: enqueue this thread's chunks of the current K step into `tile` (LDS) and advance
+  __device__ __forceinline__ void issue(const GemmParams& p, int klimit, char* tile) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if constexpr (MODE == OPM_DENSE_K) {
-        if (ok[i] && kk[i] < klimit) v = *reinterpret_cast<const uint4*>(ptr[i]);
-        ptr[i] += KT;
-        kk[i] += KT;
-      } else if constexpr (MODE == OPM_DENSE_MN) {
-        if (ok[i] && kk[i] < klimit) v = *reinterpret_cast<const uint4*>(ptr[i]);
-        ptr[i] += (long)KT * ld;
-        kk[i] += KT;
-      } else if constexpr (MODE == OPM_CONV_FWD) {
-        const int hi = a0[i] + a2[i], wi = a1[i] + a3[i];
-        if (ok[i] && a2[i] < p.cKH && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
-          v = *reinterpret_cast<const uint4*>(base + boff[i] + ((long)(hi * p.cW + wi) << p.cLogC) + a4[i]);
-        int cin = a4[i] + KT;
-        a3[i] += cin >> p.cLogC;
-        a4[i] = cin & (p.cC - 1);
-        while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
-      } else if constexpr (MODE == OPM_CONV_DGRAD) {
-        const int th = a0[i] - a2[i], tw = a1[i] - a3[i];
-        const int sm = p.cS - 1;
-        const int ho = th >> p.cLogS, wo = tw >> p.cLogS;
-        if (ok[i] && a2[i] < p.cKH && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && ho < p.cHo && wo < p.cWo)
-          v = *reinterpret_cast<const uint4*>(base + boff[i] + ((long)(ho * p.cWo + wo) << p.cLogC) + a4[i]);
-        int co = a4[i] + KT;
-        a3[i] += co >> p.cLogC;
-        a4[i] = co & (p.cC - 1);
-        while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
-      } else {
-        const int hi = a0[i] * p.cS - p.cP + a3[i], wi = a1[i] * p.cS - p.cP + a4[i];
-        if (ok[i] && kk[i] < klimit && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
-          v = *reinterpret_cast<const uint4*>(base + ((((long)a2[i] * p.cH + hi) * p.cW + wi) << p.cLogC) + boff[i]);
-        kk[i] += KT;
-        a1[i] += KT;
-        while (a1[i] >= p.cWo) {
-          a1[i] -= p.cWo;
-          if (++a0[i] == p.cHo) { a0[i] = 0; ++a2[i]; }
-        }
-      }
-      regs[i] = v;
+      const uint32_t v = next_offset(p, klimit, i);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (wave * NCH + i) * 1024), 16, v, 0, 0, 0);
     }
   }
 
-  __device__ __forceinline__ void store(char* tile, const uint4 (&regs)[NCH]) const {
-    const int tid = threadIdx.x;
+  // register path (mn-major fp32): load now, transpose into LDS later
+  __device__ __forceinline__ void load(const GemmParams& p, int klimit, uint4 (&regs)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int id = tid + i * 256;
-      if constexpr (mode_is_kmajor<MODE>::value) {
-        *reinterpret_cast<uint4*>(tile + lds_chunk_off(id >> 2, id & 3)) = regs[i];
-      } else {
-        // transpose on the write: element j of the chunk is (row cc*VEC+j, k = r)
-        const int r = id / CPR, cc = id % CPR;
-        const int kb = r * (int)sizeof(T);
-        const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+      const uint32_t v = next_offset(p, klimit, i);
+      regs[i] = (v == DMA_OOB) ? make_uint4(0, 0, 0, 0)
+                               : *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + v);
+    }
+  }
+  __device__ __forceinline__ void store(char* tile, const uint4 (&regs)[NCH]) const {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const int row = cc * VEC + j;
-          char* dst = tile + lds_chunk_off(row, kb >> 4) + (kb & 15);
-          if constexpr (sizeof(T) == 2)
-            *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
-          else
-            *reinterpret_cast<uint32_t*>(dst) = w[j];
-        }
+    for (int i = 0; i < NCH; ++i) {
+      int r, cc;
+      slot(i, r, cc);
+      const int kb = r * (int)sizeof(T);
+      const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int row = cc * VEC + j;
+        *reinterpret_cast<uint32_t*>(tile + lds_chunk_off(row, kb >> 4) + (kb & 15)) = w[j];
       }
     }
   }
 };
+
+// XCD-aware bijective remap of the linear workgroup id (8 XCDs, round-robin dispatch): ids that share an XCD get a
+// contiguous range of tiles, so the n-tiles of one activation row-block hit one L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, l = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int AMODE, int BMODE, int BN>
@@ -198,12 +253,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int KT = 64 / sizeof(T);
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+  using LA = OperandLoader<T, AMODE, BM>;
+  using LB = OperandLoader<T, BMODE, BN>;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * (A_BYTES + B_BYTES)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x % ntn;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / ntn, tile_n = bid % ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int zz = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
   const int zo = zz / p.batch_inner, zi = zz % p.batch_inner;
@@ -215,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int kt_begin = split * p.tiles_per_split;
   const int kt_end = min(nk_total, kt_begin + p.tiles_per_split);
 
-  OperandLoader<T, AMODE, BM> la;
-  OperandLoader<T, BMODE, BN> lb;
+  LA la;
+  LB lb;
   la.init(p, Ab, p.lda, p.M, m0, kt_begin * KT);
   lb.init(p, Bb, p.ldb, p.N, n0, kt_begin * KT);
 
@@ -228,36 +286,64 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[OperandLoader<T, AMODE, BM>::NCH], rb[OperandLoader<T, BMODE, BN>::NCH];
+  uint4 ra[LA::NCH], rb[LB::NCH];
 
   if (kt_begin < kt_end) {
-    la.load(p, Ab, p.lda, p.K, ra);
-    lb.load(p, Bb, p.ldb, p.K, rb);
-    la.store(smem, ra);
-    lb.store(smem + A_BYTES, rb);
+    if constexpr (LA::DMA) la.issue(p, p.K, smem); else { la.load(p, p.K, ra); la.store(smem, ra); }
+    if constexpr (LB::DMA) lb.issue(p, p.K, smem + A_BYTES); else { lb.load(p, p.K, rb); lb.store(smem + A_BYTES, rb); }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  const int lr = lane & 31, lh = lane >> 5;
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = (kt + 1 < kt_end);
+    char* nxt = smem + (cur ^ 1) * (A_BYTES + B_BYTES);
     if (more) {
-      la.load(p, Ab, p.lda, p.K, ra);
-      lb.load(p, Bb, p.ldb, p.K, rb);
+      if constexpr (LA::DMA) la.issue(p, p.K, nxt); else la.load(p, p.K, ra);
+      if constexpr (LB::DMA) lb.issue(p, p.K, nxt + A_BYTES); else lb.load(p, p.K, rb);
     }
     const char* As = smem + cur * (A_BYTES + B_BYTES);
     const char* Bs = As + A_BYTES;
-    const int lr = lane & 31, lh = lane >> 5;
     if constexpr (sizeof(T) == 2) {
+      // lane geometry of the transposed read (mn-major images): 16-lane group g, row q / column quad pq inside it
+      const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         mfma_bf16x8_t fa[MI], fb[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-          fa[i] = *reinterpret_cast<const mfma_bf16x8_t*>(As + lds_chunk_off(wm * WM + i * 32 + lr, 2 * ks + lh));
+        for (int i = 0; i < MI; ++i) {
+          if constexpr (LA::KM) {
+            fa[i] = *reinterpret_cast<const mfma_bf16x8_t*>(As + lds_chunk_off(wm * WM + i * 32 + lr, 2 * ks + lh));
+          } else {
+            const int col = wm * WM + i * 32 + 16 * (tg & 1) + 4 * tp;
+            const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                As + k0r * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r)) << 4) + (tp & 1) * 8));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                As + (k0r + 4) * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            fa[i] = __builtin_bit_cast(mfma_bf16x8_t, v);
+          }
+        }
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          fb[j] = *reinterpret_cast<const mfma_bf16x8_t*>(Bs + lds_chunk_off(wn * WN + j * 32 + lr, 2 * ks + lh));
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (LB::KM) {
+            fb[j] = *reinterpret_cast<const mfma_bf16x8_t*>(Bs + lds_chunk_off(wn * WN + j * 32 + lr, 2 * ks + lh));
+          } else {
+            const int col = wn * WN + j * 32 + 16 * (tg & 1) + 4 * tp;
+            const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                Bs + k0r * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r)) << 4) + (tp & 1) * 8));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                Bs + (k0r + 4) * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            fb[j] = __builtin_bit_cast(mfma_bf16x8_t, v);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -283,16 +369,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       }
     }
     if (more) {
-      char* An = smem + (cur ^ 1) * (A_BYTES + B_BYTES);
-      la.store(An, ra);
-      lb.store(An + A_BYTES, rb);
+      if constexpr (!LA::DMA) la.store(nxt, ra);
+      if constexpr (!LB::DMA) lb.store(nxt + A_BYTES, rb);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of step t+1 has landed (this wave's part) ...
+    __syncthreads();                                    // ... and so has everyone else's
     cur ^= 1;
   }
 
   // ---------------------------------------------------------------- epilogue
-  const int lr = lane & 31, lh = lane >> 5;
   if (p.nsplit > 1 || p.out_f32) {
     float* Cf = reinterpret_cast<float*>(p.C) + (p.nsplit > 1 ? (long)split * p.M * p.ldc : (zo * p.sc_o + zi * p.sc_i));
 #pragma unroll
@@ -356,11 +441,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 }
 
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i]   (fixed order: bitwise reproducible)
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n, int nsplit, int accumulate) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float s = accumulate ? out[i] : 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(long)k * n + i];
-    out[i] = s;
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n4, int nsplit, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 s = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nsplit; ++k) {
+      const float4 t = reinterpret_cast<const float4*>(slab)[(long)k * n4 + i];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
   }
 }
 
@@ -396,15 +484,18 @@ static GemmParams base_params() {
 
 static inline int vec_of(int dtype) { return dtype == MSC_F32 ? 4 : 8; }
 static inline int kt_of(int dtype) { return dtype == MSC_F32 ? 16 : 32; }
+static inline int esize(int dtype) { return dtype == MSC_F32 ? 4 : 2; }
+// every operand is addressed with 32-bit byte offsets below DMA_OOB
+static inline bool fits32(long elems, int dtype) { return elems * esize(dtype) < 0x7ffffff0L; }
 
 // split-K plan shared by the workspace query and the launchers (independent of dtype)
 static int plan_split(long rows_out, long cols_out, long reduce_len) {
   const long tiles = (long)cdiv(rows_out, 128) * cdiv(cols_out, cols_out <= 64 ? 64 : 128);
-  long want = 1024 / (tiles > 0 ? tiles : 1);
-  long cap = reduce_len / 512;
+  long want = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  long cap = reduce_len / 1024;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
-  if (want > 512) want = 512;
+  if (want > 128) want = 128;
   return (int)want;
 }
 
@@ -420,19 +511,19 @@ static int finish_wgrad(GemmParams& p, float* dw, float* ws, int64_t ws_bytes, l
   int tps = cdiv(nk, ns);
   ns = cdiv(nk, tps);
   if ((int64_t)ns * p.M * p.N * 4 > ws_bytes || !ws) return MSC_ERR_BAD_ARG;
+  if (((long)p.M * p.N) % 4) return MSC_ERR_BAD_ARG;
   p.nsplit = ns;
   p.tiles_per_split = tps;
   p.C = ws;
   p.ldc = p.N;
   p.out_f32 = 1;
   // nsplit == 1 still goes through the slab so that `accumulate` has one implementation
-  if (ns == 1) { p.sc_o = 0; p.sc_i = 0; }
   int rc = launch(p, 1, dtype, st);
   if (rc != MSC_OK) return rc;
-  const long n = (long)p.M * p.N;
-  int blocks = cdiv(n, 256);
+  const long n4 = (long)p.M * p.N / 4;
+  int blocks = cdiv(n4, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, n, ns, accumulate);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, n4, ns, accumulate);
   return msc_launch_status();
 }
 
@@ -450,6 +541,7 @@ extern "C" int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_p
   MSC_CHECK_ARG(Cin >= vec_of(dtype) && ilog2_exact(Cin) >= 0 && Cout > 0);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   MSC_CHECK_ARG(Ho > 0 && Wo > 0);
+  if (!fits32((long)B * H * W * Cin, dtype) || !fits32((long)Cout * KH * KW * Cin, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = x; p.B = w; p.C = y; p.stats = bn_partial;
   p.M = B * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin;
@@ -465,6 +557,7 @@ extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res,
   MSC_CHECK_ARG(Cout >= vec_of(dtype) && ilog2_exact(Cout) >= 0 && Cin > 0 && ilog2_exact(stride) >= 0);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   MSC_CHECK_ARG(Ho > 0 && Wo > 0);
+  if (!fits32((long)B * Ho * Wo * Cout, dtype) || !fits32((long)Cout * KH * KW * Cin, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = dy; p.B = wt; p.C = dx; p.res = res;
   p.M = B * H * W; p.N = Cin; p.K = KH * KW * Cout;
@@ -481,6 +574,7 @@ extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   MSC_CHECK_ARG(Cin >= vec_of(dtype) && ilog2_exact(Cin) >= 0 && Cout % vec_of(dtype) == 0);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   MSC_CHECK_ARG(Ho > 0 && Wo > 0);
+  if (!fits32((long)B * H * W * Cin, dtype) || !fits32((long)B * Ho * Wo * Cout, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = dy; p.B = x;
   p.M = Cout; p.N = KH * KW * Cin; p.K = B * Ho * Wo;
@@ -495,6 +589,7 @@ extern "C" int msc_linear_fwd(const void* x, const void* w, const float* bias, c
   MSC_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(K % vec_of(dtype) == 0);
+  if (!fits32((long)M * K, dtype) || !fits32((long)N * K, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = x; p.B = w; p.C = y; p.C2 = pre; p.res = res; p.bias = bias; p.act = act;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
@@ -505,6 +600,7 @@ extern "C" int msc_linear_dgrad(const void* dy, const void* wt, void* dx, int M,
   MSC_CHECK_ARG(dy && wt && dx && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(N % vec_of(dtype) == 0);
+  if (!fits32((long)M * N, dtype) || !fits32((long)N * K, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = dy; p.B = wt; p.C = dx;
   p.M = M; p.N = K; p.K = N; p.lda = N; p.ldb = N; p.ldc = K;
@@ -516,6 +612,7 @@ extern "C" int msc_linear_wgrad(const void* x, const void* dy, float* dw, float*
   MSC_CHECK_ARG(x && dy && dw && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(N % vec_of(dtype) == 0 && K % vec_of(dtype) == 0);
+  if (!fits32((long)M * N, dtype) || !fits32((long)M * K, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = dy; p.B = x;
   p.M = N; p.N = K; p.K = M; p.lda = N; p.ldb = K;
@@ -532,6 +629,7 @@ extern "C" int msc_gemm_batched(const void* A, const void* Bm, void* C, int M, i
   const int V = vec_of(dtype);
   MSC_CHECK_ARG(lda % V == 0 && ldb % V == 0 && sa_o % V == 0 && sa_i % V == 0 && sb_o % V == 0 && sb_i % V == 0);
   // rows may end inside a 16-byte chunk as long as the padded tail (up to ld) is readable and finite/zero
+  if (!fits32((long)(a_kmajor ? M : K) * lda, dtype) || !fits32((long)(b_kmajor ? N : K) * ldb, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = A; p.B = Bm; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
