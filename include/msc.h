@@ -41,8 +41,9 @@ int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t re
  * ImageEncoder / BEV conv stack: implicit-GEMM convolution (no im2col buffer).
  * x:[B,H,W,Cin] w:[Cout,KH,KW,Cin] y:[B,Ho,Wo,Cout], Ho=(H+2p-KH)/s+1.  Cin must be a power of two
  * >= 16/sizeof(T) (the RGB image is padded to 8 channels by msc_image_to_nhwc).
- * bn_partial (may be NULL): fp32 [ceil(B*Ho*Wo/128)][2][Cout] per-row-block column sums / sums of
- * squares of the fp32 accumulators, reduced in fixed order by msc_bn_finalize (deterministic). */
+ * bn_partial (may be NULL): fp32 [msc_conv2d_fwd_stat_rows(B*Ho*Wo, Cout)][2][Cout] per-row-block column
+ * sums / sums of squares of the fp32 accumulators, reduced in fixed order by msc_bn_finalize (deterministic). */
+int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout);
 int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_partial, int B, int H, int W,
                    int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream);
 /* dx:[B,H,W,Cin] = conv-transpose of dy:[B,Ho,Wo,Cout] with wt:[Cin,KH,KW,Cout] (msc_permute3_cast)

@@ -247,15 +247,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int AMODE, int BMODE, int BN>
+template <typename T, int AMODE, int BMODE, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-  constexpr int BM = 128;
   constexpr int KT = 64 / sizeof(T);
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  constexpr int EP_BYTES = 64 * BN * 4;     // epilogue slab: 64 rows x BN fp32
+  constexpr int SMEM_BYTES = 2 * (A_BYTES + B_BYTES) > EP_BYTES ? 2 * (A_BYTES + B_BYTES) : EP_BYTES;
   using LA = OperandLoader<T, AMODE, BM>;
   using LB = OperandLoader<T, BMODE, BN>;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * (A_BYTES + B_BYTES)];
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -378,65 +379,129 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   }
 
   // ---------------------------------------------------------------- epilogue
-  if (p.nsplit > 1 || p.out_f32) {
-    float* Cf = reinterpret_cast<float*>(p.C) + (p.nsplit > 1 ? (long)split * p.M * p.ldc : (zo * p.sc_o + zi * p.sc_i));
+  // (1) BatchNorm partial statistics straight from the fp32 accumulators (conv forward only)
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [2 wm][2 stat][BN]
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * WN + j * 32 + lr;
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < p.M && n < p.N) Cf[(long)m * p.ldc + n] = p.alpha * acc[i][j][r];
-        }
-      }
-    return;
-  }
-
-  T* Cb = reinterpret_cast<T*>(p.C) + zo * p.sc_o + zi * p.sc_i;
-  T* C2 = reinterpret_cast<T*>(p.C2);
-  const T* Rs = reinterpret_cast<const T*>(p.res);
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wn * WN + j * 32 + lr;
-    const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float v = p.alpha * acc[i][j][r] + bv;
-        s1 += v;
-        s2 += v * v;
-        if (m < p.M && n < p.N) {
-          const long o = (long)m * p.ldc + n;
-          if (C2) msc_traits<T>::st(C2 + o, v);
-          v = act_apply(v, p.act);
-          if (Rs) v += msc_traits<T>::ld(Rs + o);
-          msc_traits<T>::st(Cb + o, v);
-        }
-      }
-    }
-    if (p.stats) {
-      // rows beyond M were loaded as zeros and conv has no bias, so they add nothing to the sums
+        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+      // rows beyond M were staged as zeros and conv has no bias, so they add nothing to the sums
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      float* red = reinterpret_cast<float*>(smem);  // [2 wm][2 stat][BN]
-      __syncthreads();
       if (lh == 0) {
         red[(wm * 2 + 0) * BN + wn * WN + j * 32 + lr] = s1;
         red[(wm * 2 + 1) * BN + wn * WN + j * 32 + lr] = s2;
       }
-      __syncthreads();
-      if (wm == 0 && lh == 0 && n < p.N) {
-        const int c = wn * WN + j * 32 + lr;
-        float* st = p.stats + (long)tile_m * 2 * p.N;
-        st[n] = red[(0 * 2 + 0) * BN + c] + red[(1 * 2 + 0) * BN + c];
-        st[p.N + n] = red[(0 * 2 + 1) * BN + c] + red[(1 * 2 + 1) * BN + c];
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float* st = p.stats + (long)tile_m * 2 * p.N;
+      st[n0 + tid] = red[(0 * 2 + 0) * BN + tid] + red[(1 * 2 + 0) * BN + tid];
+      st[p.N + n0 + tid] = red[(0 * 2 + 1) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+    }
+    __syncthreads();
+  }
+
+  // (2) accumulators -> LDS slab (fp32, 64 rows per pass) -> 16-byte coalesced global stores with the fused
+  //     bias / pre-activation copy / activation / residual applied on whole vectors
+  float* slab = reinterpret_cast<float*>(smem);
+  const bool f32out = (p.nsplit > 1 || p.out_f32);
+  char* Cbase = f32out ? reinterpret_cast<char*>(reinterpret_cast<float*>(p.C) + (p.nsplit > 1 ? (long)split * p.M * p.ldc : (zo * p.sc_o + zi * p.sc_i)))
+                       : reinterpret_cast<char*>(reinterpret_cast<T*>(p.C) + zo * p.sc_o + zi * p.sc_i);
+  constexpr int PASSES = BM / 64;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const bool mine = (PASSES == 1) || (wm == ps);
+    if (mine) {
+      const int rbase = (PASSES == 1) ? wm * WM : 0;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            slab[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WN + j * 32 + lr] = p.alpha * acc[i][j][r];
+    }
+    __syncthreads();
+    if (f32out) {
+      constexpr int CPRW = BN / 4;
+#pragma unroll
+      for (int it = 0; it < 64 * CPRW / 256; ++it) {
+        const int id = tid + it * 256;
+        const int row = id / CPRW, cc = id % CPRW;
+        const int m = m0 + ps * 64 + row, n = n0 + cc * 4;
+        if (m >= p.M || n >= p.N) continue;
+        const float4 v = *reinterpret_cast<const float4*>(slab + row * BN + cc * 4);
+        float* dst = reinterpret_cast<float*>(Cbase) + (long)m * p.ldc + n;
+        if (n + 4 <= p.N && (p.ldc & 3) == 0) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = vv[e];
+        }
+      }
+    } else {
+      constexpr int VEC = 16 / sizeof(T);
+      constexpr int CPRW = BN / VEC;
+      T* C2 = reinterpret_cast<T*>(p.C2);
+      const T* Rs = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+      for (int it = 0; it < 64 * CPRW / 256; ++it) {
+        const int id = tid + it * 256;
+        const int row = id / CPRW, cc = id % CPRW;
+        const int m = m0 + ps * 64 + row, n = n0 + cc * VEC;
+        if (m >= p.M || n >= p.N) continue;
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(slab + row * BN + cc * VEC + e);
+          v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+        }
+        const long o = (long)m * p.ldc + n;
+        T* dst = reinterpret_cast<T*>(Cbase) + o;
+        if (n + VEC <= p.N && (p.ldc % VEC) == 0) {
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+              const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n + e);
+              v[e] += b4.x; v[e + 1] += b4.y; v[e + 2] += b4.z; v[e + 3] += b4.w;
+            }
+          }
+          vecf<T> vo;
+          if (C2) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) vo.v[e] = v[e];
+            vo.store(C2 + o);
+          }
+          if (p.act != MSC_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = act_apply(v[e], p.act);
+          }
+          if (Rs) {
+            vecf<T> vr;
+            vr.load(Rs + o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += vr.v[e];
+          }
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) vo.v[e] = v[e];
+          vo.store(dst);
+        } else {
+          for (int e = 0; e < VEC && n + e < p.N; ++e) {
+            float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
+            if (C2) msc_traits<T>::st(C2 + o + e, x);
+            x = act_apply(x, p.act);
+            if (Rs) x += msc_traits<T>::ld(Rs + o + e);
+            msc_traits<T>::st(dst + e, x);
+          }
+        }
       }
     }
+    if (ps + 1 < PASSES) __syncthreads();
   }
 }
 
@@ -453,15 +518,32 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// tile choice: narrow operands get 64-wide tiles; launches that would leave most of the 256 CUs idle trade MFMA work
+// per LDS byte for more workgroups
+static void choose_tile(long M, long N, long zs, int& bm, int& bn) {
+  bm = M <= 64 ? 64 : 128;
+  bn = N <= 64 ? 64 : 128;
+  if (bn == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bn = 64;
+  if (bm == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bm = 64;
+}
+
+// rows of the BatchNorm partial-statistics buffer msc_conv2d_fwd writes for an output of `rows` pixels x `cout`
+extern "C" int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout) {
+  int bm, bn;
+  choose_tile(rows, cout, 1, bm, bn);
+  return cdiv(rows, bm);
+}
+
 template <typename T, int AMODE, int BMODE>
 static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
-  const bool narrow = p.N <= 64;
-  const int BN = narrow ? 64 : 128;
-  dim3 grid((unsigned)(cdiv(p.M, 128) * cdiv(p.N, BN)), 1, (unsigned)(batch * p.nsplit));
-  if (narrow)
-    hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64>), grid, dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128>), grid, dim3(256), 0, st, p);
+  int bm, bn;
+  const long zs = (long)batch * p.nsplit;
+  choose_tile(p.M, p.N, zs, bm, bn);
+  dim3 grid((unsigned)(cdiv(p.M, bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128>), grid, dim3(256), 0, st, p);
+  else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64>), grid, dim3(256), 0, st, p);
+  else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64>), grid, dim3(256), 0, st, p);
   return msc_launch_status();
 }
 

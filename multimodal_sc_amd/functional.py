@@ -29,7 +29,7 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     M = B * Ho * Wo
-    nblk = _cdiv(M, 128)
+    nblk = L.query("msc_conv2d_fwd_stat_rows", M, Cout)
     y_raw = rt.empty(B, Ho, Wo, Cout)
     partial = rt.workspace("bn_partial", nblk * 2 * Cout * 4)
     rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.dt)

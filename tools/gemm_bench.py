@@ -54,7 +54,7 @@ for name, H, Cin, Cout, K, s, p in convs:
     Ho = (H + 2 * p - K) // s + 1
     x, w = rnd(B, H, H, Cin), rnd(Cout, K, K, Cin)
     y = rnd(B, Ho, Ho, Cout)
-    part = torch.empty((B * Ho * Ho + 127) // 128 * 2 * Cout, device=dev)
+    part = torch.empty((B * Ho * Ho + 63) // 64 * 2 * Cout, device=dev)
     cin_real = 3 if Cin == 8 else Cin
     fl = 2.0 * B * Ho * Ho * Cout * K * K * cin_real
     t = timeit(lambda: rt.call("msc_conv2d_fwd", x, w, y, part, B, H, H, Cin, Cout, K, K, s, p, rt.dt))
