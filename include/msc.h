@@ -101,8 +101,8 @@ int64_t msc_layernorm_bwd_workspace_bytes(int64_t rows, int D);
 int msc_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       const void* dadd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
                       int accumulate, int dtype, void* stream);
-/* out[c] (+)= sum_r x[r][c] — bias and positional-embedding gradients.  ws >= msc_colsum_workspace_bytes(cols) */
-int64_t msc_colsum_workspace_bytes(int64_t cols);
+/* out[c] (+)= sum_r x[r][c] — bias and positional-embedding gradients.  ws >= msc_colsum_workspace_bytes(rows, cols) */
+int64_t msc_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int msc_colsum(const void* x, float* out, float* ws, int64_t rows, int64_t cols, int accumulate, int dtype,
                void* stream);
 
@@ -126,6 +126,11 @@ int msc_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, i
 int msc_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
 /* dst[k][j][i] = src[i][j][k]; OHWI -> [Cin][KH*KW][Cout] with (d0,d1,d2)=(Cout,KH*KW,Cin); linear W^T with d1=1 */
 int msc_permute3_cast(const float* src, void* dst, int d0, int d1, int d2, int dtype, void* stream);
+/* every weight transpose of a step in one launch.  table (device, int64 [n][6]) = {src_off, dst_off, d0, d1, d2,
+ * first_block}: offsets in elements into the flat fp32 parameter buffer P / the flat transposed buffer TR;
+ * first_block = running sum of ceil(d2/32)*ceil(d0/32)*d1; total_blocks = that sum over all entries. */
+int msc_permute3_cast_batched(const float* P, void* TR, const int64_t* table, int n_entries, int total_blocks,
+                              int dtype, void* stream);
 /* torch.optim.Adam semantics; shadow (T, may be NULL) receives the updated low-precision copy */
 int msc_adam_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, int dtype, void* stream);

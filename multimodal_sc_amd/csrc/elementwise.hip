@@ -198,7 +198,7 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ r
         case MSC_ACT_RELU: d = y > 0.f ? 1.f : 0.f; break;
         case MSC_ACT_TANH: d = 1.f - y * y; break;
         case MSC_ACT_SIGMOID: d = y * (1.f - y); break;
-        case MSC_ACT_GELU: d = 0.5f * (1.f + erff(y * 0.70710678118654752f)) + y * 0.3989422804014327f * __expf(-0.5f * y * y); break;
+        case MSC_ACT_GELU: d = 0.5f * (1.f + fast_erf(y * 0.70710678118654752f)) + y * 0.3989422804014327f * __expf(-0.5f * y * y); break;
         default: d = 1.f;
       }
       g.v[j] *= d;
@@ -220,6 +220,35 @@ __global__ void permute3_cast_kernel(const float* __restrict__ src, T* __restric
   const int j = blockIdx.z;
   const int i0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, k = k0 + tx;
+    tile[r][tx] = (i < d0 && k < d2) ? src[((long)i * d1 + j) * d2 + k] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, i = i0 + tx;
+    if (k < d2 && i < d0) msc_traits<T>::st(dst + ((long)k * d1 + j) * d0 + i, tile[tx][r]);
+  }
+}
+
+// All weight transposes of a step in ONE launch.  table: int64 [n][6] = {src_off, dst_off, d0, d1, d2, first_block}
+// (offsets in elements into the flat fp32 parameter buffer / the flat transposed buffer).
+template <typename T>
+__global__ void permute3_cast_batched_kernel(const float* __restrict__ P, T* __restrict__ TR, const int64_t* __restrict__ table, int n) {
+  __shared__ float tile[32][33];
+  int e = 0;
+  while (e + 1 < n && (long)blockIdx.x >= table[(e + 1) * 6 + 5]) ++e;
+  const int64_t* d = table + e * 6;
+  const float* src = P + d[0];
+  T* dst = TR + d[1];
+  const int d0 = (int)d[2], d1 = (int)d[3], d2 = (int)d[4];
+  int local = (int)((long)blockIdx.x - d[5]);
+  const int nbx = (d2 + 31) / 32, nby = (d0 + 31) / 32;
+  const int bx = local % nbx; local /= nbx;
+  const int by = local % nby;
+  const int j = local / nby;
+  const int i0 = by * 32, k0 = bx * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int r = ty; r < 32; r += 8) {
     const int i = i0 + r, k = k0 + tx;
     tile[r][tx] = (i < d0 && k < d2) ? src[((long)i * d1 + j) * d2 + k] : 0.f;
@@ -330,6 +359,14 @@ extern "C" int msc_permute3_cast(const float* src, void* dst, int d0, int d1, in
   MSC_CHECK_ARG(src && dst && d0 > 0 && d1 > 0 && d2 > 0 && d1 <= 65535);
   dim3 grid((unsigned)cdiv(d2, 32), (unsigned)cdiv(d0, 32), (unsigned)d1);
   DISPATCH_T(dtype, hipLaunchKernelGGL(permute3_cast_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst, d0, d1, d2));
+  return msc_launch_status();
+}
+
+extern "C" int msc_permute3_cast_batched(const float* P, void* TR, const int64_t* table, int n_entries, int total_blocks, int dtype,
+                                         void* stream) {
+  MSC_CHECK_ARG(P && TR && table && n_entries > 0 && total_blocks > 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(permute3_cast_batched_kernel<T>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, P,
+                                       (T*)TR, table, n_entries));
   return msc_launch_status();
 }
 

@@ -38,6 +38,7 @@ struct GemmParams {
   float alpha; int act; int out_f32;
   // geometry of the gathered NHWC tensor (conv modes)
   int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
+  int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
@@ -51,6 +52,29 @@ __device__ __forceinline__ int lds_chunk_off(int row, int c) { return row * 64 +
 // swizzle of the 16-byte chunk index inside an mn-major LDS row of ROWB bytes, keyed by the k row
 template <int ROWB> __device__ __forceinline__ int mn_swz(int krow) {
   return ROWB == 256 ? ((krow & 3) << 2) : (((krow >> 1) & 1) << 2);
+}
+
+// One K step of the schedule: kbase = first reduction index of the step; (kh, kw, co0) = its filter tap and first
+// channel for the dgrad gather.  Wave-uniform.
+struct KStep { int kbase, kh, kw, co0; };
+
+// Strided dgrad orders its rows (input pixels) parity-class-major: class (h%S, w%S) first, then (b, h/S, w/S).  All
+// rows of a class see the same subset of filter taps ((h+P-kh) % S == 0), so a tile inside one class iterates only
+// those taps instead of multiplying 3/4 zeros (stride 2).  p.cls == 0: plain (b,h,w) order.
+__device__ __forceinline__ void dgrad_row_to_pixel(const GemmParams& p, int row, int& b, int& h, int& w) {
+  if (p.cls) {
+    const int cid = row / p.cMc, idx = row - cid * p.cMc;
+    const int w2 = idx % p.cW2, t = idx / p.cW2;
+    const int h2 = t % p.cH2;
+    b = t / p.cH2;
+    h = h2 * p.cS + cid / p.cS;
+    w = w2 * p.cS + cid % p.cS;
+  } else {
+    w = row % p.cW;
+    const int t = row / p.cW;
+    h = t % p.cH;
+    b = t / p.cH;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -104,9 +128,10 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
       int r, c;
       slot(i, r, c);
       if constexpr (MODE == OPM_DENSE_K) {
+        // seek-based: the K step's base index comes from the schedule (KStep), so a strided dgrad can skip taps
         const int row = row0 + r;
         ok[i] = row < rows_total;
-        kk[i] = k0 + c * VEC;
+        kk[i] = c * VEC;
         off[i] = (uint32_t)(((long)(ok[i] ? row : 0) * ld + kk[i]) * (long)sizeof(T));
       } else if constexpr (MODE == OPM_DENSE_MN) {
         const int col = row0 + c * VEC;
@@ -131,17 +156,12 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
         // rows are INPUT pixels (b,h,w) of size cH x cW; gathered tensor is dy [cB,cHo,cWo,cC]
         const int row = row0 + r;
         ok[i] = row < rows_total;
-        const int rr = ok[i] ? row : 0;
-        const int w = rr % p.cW, t = rr / p.cW;
-        const int h = t % p.cH, bb = t / p.cH;
+        int h, w, bb;
+        dgrad_row_to_pixel(p, ok[i] ? row : 0, bb, h, w);
         a0[i] = h + p.cP;
         a1[i] = w + p.cP;
         boff[i] = (uint32_t)bb * (uint32_t)(p.cHo * p.cWo * p.cC);
-        const int k = k0 + c * VEC;
-        const int tap = k >> p.cLogC;
-        a4[i] = k & (p.cC - 1);
-        a2[i] = tap / p.cKW;
-        a3[i] = tap - a2[i] * p.cKW;
+        a4[i] = c * VEC;      // channel offset inside the K step; (kh, kw, co0) come from the schedule
       } else {  // OPM_CONV_WGRAD: columns n=(kh,kw,cin) fixed per thread, reduction over (b,ho,wo)
         const int col = row0 + c * VEC;
         ok[i] = col < rows_total;
@@ -161,12 +181,10 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
   }
 
   // byte offset of slot i's chunk for the current K step (DMA_OOB where the element is padding), then advance
-  __device__ __forceinline__ uint32_t next_offset(const GemmParams& p, int klimit, int i) {
+  __device__ __forceinline__ uint32_t next_offset(const GemmParams& p, int klimit, int i, const KStep& ks) {
     uint32_t v = DMA_OOB;
     if constexpr (MODE == OPM_DENSE_K) {
-      if (ok[i] && kk[i] < klimit) v = off[i];
-      off[i] += 64;
-      kk[i] += KT;
+      if (ok[i] && ks.kbase + kk[i] < klimit) v = off[i] + (uint32_t)ks.kbase * (uint32_t)sizeof(T);
     } else if constexpr (MODE == OPM_DENSE_MN) {
       if (ok[i] && kk[i] < klimit) v = off[i];
       off[i] += (uint32_t)(KT * ld * (long)sizeof(T));
@@ -180,15 +198,11 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
       a4[i] = cin & (p.cC - 1);
       while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
     } else if constexpr (MODE == OPM_CONV_DGRAD) {
-      const int th = a0[i] - a2[i], tw = a1[i] - a3[i];
+      const int th = a0[i] - ks.kh, tw = a1[i] - ks.kw;
       const int sm = p.cS - 1;
       const int ho = th >> p.cLogS, wo = tw >> p.cLogS;
-      if (ok[i] && a2[i] < p.cKH && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && ho < p.cHo && wo < p.cWo)
-        v = (boff[i] + ((uint32_t)(ho * p.cWo + wo) << p.cLogC) + (uint32_t)a4[i]) * (uint32_t)sizeof(T);
-      const int co = a4[i] + KT;
-      a3[i] += co >> p.cLogC;
-      a4[i] = co & (p.cC - 1);
-      while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
+      if (ok[i] && ks.kh < p.cKH && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && ho < p.cHo && wo < p.cWo)
+        v = (boff[i] + ((uint32_t)(ho * p.cWo + wo) << p.cLogC) + (uint32_t)(ks.co0 + a4[i])) * (uint32_t)sizeof(T);
     } else {
       const int hi = a0[i] * p.cS - p.cP + a3[i], wi = a1[i] * p.cS - p.cP + a4[i];
       if (ok[i] && kk[i] < klimit && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
@@ -205,20 +219,20 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
   }
 
   // DMA path: enqueue this thread's chunks of the current K step into `tile` (LDS) and advance
-  __device__ __forceinline__ void issue(const GemmParams& p, int klimit, char* tile) {
+  __device__ __forceinline__ void issue(const GemmParams& p, int klimit, char* tile, const KStep& ks) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const uint32_t v = next_offset(p, klimit, i);
+      const uint32_t v = next_offset(p, klimit, i, ks);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (wave * NCH + i) * 1024), 16, v, 0, 0, 0);
     }
   }
 
   // register path (mn-major fp32): load now, transpose into LDS later
-  __device__ __forceinline__ void load(const GemmParams& p, int klimit, uint4 (&regs)[NCH]) {
+  __device__ __forceinline__ void load(const GemmParams& p, int klimit, uint4 (&regs)[NCH], const KStep& ks) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const uint32_t v = next_offset(p, klimit, i);
+      const uint32_t v = next_offset(p, klimit, i, ks);
       regs[i] = (v == DMA_OOB) ? make_uint4(0, 0, 0, 0)
                                : *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + v);
     }
@@ -274,6 +288,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int kt_begin = split * p.tiles_per_split;
   const int kt_end = min(nk_total, kt_begin + p.tiles_per_split);
 
+  // ---- K schedule (wave-uniform).  Default: steps kt_begin..kt_end-1, kbase = kt*KT.  Strided dgrad whose tile lies
+  // inside one parity class: only the taps that class can see, (kh0, kh0+S, ..) x (kw0, kw0+S, ..).
+  KStep ks = {kt_begin * KT, 0, 0, 0};
+  int nk = kt_end - kt_begin;
+  int s_kw0 = 0, s_step = 1;
+  if constexpr (AMODE == OPM_CONV_DGRAD) {
+    int kh0 = 0;
+    if (p.cls) {
+      const int last = min(m0 + BM, p.M) - 1;
+      const int c0 = m0 / p.cMc;
+      if (c0 == last / p.cMc) {
+        kh0 = (c0 / p.cS + p.cP) % p.cS;
+        s_kw0 = (c0 % p.cS + p.cP) % p.cS;
+        s_step = p.cS;
+      }
+    }
+    const int cnt_h = kh0 < p.cKH ? (p.cKH - kh0 + s_step - 1) / s_step : 0;
+    const int cnt_w = s_kw0 < p.cKW ? (p.cKW - s_kw0 + s_step - 1) / s_step : 0;
+    nk = cnt_h * cnt_w * (p.cC / KT);
+    ks.kh = kh0;
+    ks.kw = s_kw0;
+    ks.kbase = (kh0 * p.cKW + s_kw0) << p.cLogC;
+  }
+  auto advance = [&]() {
+    if constexpr (AMODE == OPM_CONV_DGRAD) {
+      ks.co0 += KT;
+      if (ks.co0 >= p.cC) {
+        ks.co0 = 0;
+        ks.kw += s_step;
+        if (ks.kw >= p.cKW) { ks.kw = s_kw0; ks.kh += s_step; }
+      }
+      ks.kbase = ((ks.kh * p.cKW + ks.kw) << p.cLogC) + ks.co0;
+    } else {
+      ks.kbase += KT;
+    }
+  };
+
   LA la;
   LB lb;
   la.init(p, Ab, p.lda, p.M, m0, kt_begin * KT);
@@ -289,21 +340,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
   uint4 ra[LA::NCH], rb[LB::NCH];
 
-  if (kt_begin < kt_end) {
-    if constexpr (LA::DMA) la.issue(p, p.K, smem); else { la.load(p, p.K, ra); la.store(smem, ra); }
-    if constexpr (LB::DMA) lb.issue(p, p.K, smem + A_BYTES); else { lb.load(p, p.K, rb); lb.store(smem + A_BYTES, rb); }
+  if (nk > 0) {
+    if constexpr (LA::DMA) la.issue(p, p.K, smem, ks); else { la.load(p, p.K, ra, ks); la.store(smem, ra); }
+    if constexpr (LB::DMA) lb.issue(p, p.K, smem + A_BYTES, ks); else { lb.load(p, p.K, rb, ks); lb.store(smem + A_BYTES, rb); }
+    advance();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int lr = lane & 31, lh = lane >> 5;
   int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = (kt + 1 < kt_end);
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
     char* nxt = smem + (cur ^ 1) * (A_BYTES + B_BYTES);
     if (more) {
-      if constexpr (LA::DMA) la.issue(p, p.K, nxt); else la.load(p, p.K, ra);
-      if constexpr (LB::DMA) lb.issue(p, p.K, nxt + A_BYTES); else lb.load(p, p.K, rb);
+      if constexpr (LA::DMA) la.issue(p, p.K, nxt, ks); else la.load(p, p.K, ra, ks);
+      if constexpr (LB::DMA) lb.issue(p, p.K, nxt + A_BYTES, ks); else lb.load(p, p.K, rb, ks);
+      advance();
     }
     const char* As = smem + cur * (A_BYTES + B_BYTES);
     const char* Bs = As + A_BYTES;
@@ -461,7 +514,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
           const float4 t = *reinterpret_cast<const float4*>(slab + row * BN + cc * VEC + e);
           v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
         }
-        const long o = (long)m * p.ldc + n;
+        long orow = m;
+        if constexpr (AMODE == OPM_CONV_DGRAD) {
+          if (p.cls) {   // class-major GEMM row -> NHWC pixel row
+            int bb, hh, ww;
+            dgrad_row_to_pixel(p, m, bb, hh, ww);
+            orow = ((long)bb * p.cH + hh) * p.cW + ww;
+          }
+        }
+        const long o = orow * p.ldc + n;
         T* dst = reinterpret_cast<T*>(Cbase) + o;
         if (n + VEC <= p.N && (p.ldc % VEC) == 0) {
           if (p.bias) {
@@ -645,6 +706,13 @@ extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res,
   p.M = B * H * W; p.N = Cin; p.K = KH * KW * Cout;
   p.ldb = p.K; p.ldc = Cin;
   if (set_conv_geom(p, B, H, W, Cout, Ho, Wo, KH, KW, stride, pad) != MSC_OK) return MSC_ERR_BAD_ARG;
+  MSC_CHECK_ARG(Cout % kt_of(dtype) == 0);   // a K step never straddles two filter taps
+  if (stride > 1 && H % stride == 0 && W % stride == 0) {
+    p.cls = 1;
+    p.cH2 = H / stride;
+    p.cW2 = W / stride;
+    p.cMc = B * p.cH2 * p.cW2;
+  }
   return launch_gemm_dt<OPM_CONV_DGRAD, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
 }
 

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 // ---------------------------------------------------------------- generic column sum (bias grads, dpos)
 // out[c] (+)= sum_r x[r][c];  stage 1: block = (cx column-chunks) x (256/cx row lanes) over a slab of rows
-#define COLSUM_MAX_BLOCKS 256
+#define COLSUM_MAX_BLOCKS 1024
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
                                                              long rows, long C, int rows_per_block, int cx) {
@@ -319,7 +319,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
   if (c0 < C && ty < nty) {
-    for (long r = r0 + ty; r < r1; r += nty) {
+    long r = r0 + ty;
+    for (; r + 3L * nty < r1; r += 4L * nty) {   // four independent 16-byte loads in flight per lane
+      vecf<T> v0, v1, v2, v3;
+      v0.load(x + r * C + c0);
+      v1.load(x + (r + nty) * C + c0);
+      v2.load(x + (r + 2L * nty) * C + c0);
+      v3.load(x + (r + 3L * nty) * C + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += (v0.v[j] + v1.v[j]) + (v2.v[j] + v3.v[j]);
+    }
+    for (; r < r1; r += nty) {
       vecf<T> v;
       v.load(x + r * C + c0);
 #pragma unroll
@@ -482,7 +492,18 @@ extern "C" int msc_layernorm_bwd(const void* dy, const void* x, const float* mea
   return msc_launch_status();
 }
 
-extern "C" int64_t msc_colsum_workspace_bytes(int64_t cols) { return (int64_t)COLSUM_MAX_BLOCKS * cols * 4; }
+// row-slabs: enough workgroups to fill the chip (~2048 with the column blocks), each with >= 32 rows
+static int colsum_row_blocks(long rows) {
+  long nblk = rows / 32;
+  if (nblk > 512) nblk = 512;
+  if (nblk > COLSUM_MAX_BLOCKS) nblk = COLSUM_MAX_BLOCKS;
+  if (nblk < 1) nblk = 1;
+  return (int)nblk;
+}
+
+extern "C" int64_t msc_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+  return (int64_t)colsum_row_blocks(rows) * cols * 4;
+}
 
 // out[c] (+)= sum_r x[r][c]  (x is T [rows][cols]) — bias gradients, positional-embedding gradient
 extern "C" int msc_colsum(const void* x, float* out, float* ws, int64_t rows, int64_t cols, int accumulate, int dtype,
@@ -492,13 +513,10 @@ extern "C" int msc_colsum(const void* x, float* out, float* ws, int64_t rows, in
   hipStream_t st = (hipStream_t)stream;
   const int VEC = dtype == MSC_F32 ? 4 : 8;
   MSC_CHECK_ARG(cols % VEC == 0);
-  // cx = column chunks per block: a power of two <= 256 covering the row (or 256)
+  // cx = column chunks per block: a power of two <= 64 (>= 4 row lanes per block keep loads of several rows in flight)
   int cx = 1;
-  while (cx < 256 && (long)cx * VEC < cols) cx <<= 1;
-  const int nty = 256 / cx;
-  int nblk = cdiv(rows, (long)nty * 8);
-  if (nblk > COLSUM_MAX_BLOCKS) nblk = COLSUM_MAX_BLOCKS;
-  if (nblk < 1) nblk = 1;
+  while (cx < 64 && (long)cx * VEC < cols) cx <<= 1;
+  int nblk = colsum_row_blocks(rows);
   const int rpb = cdiv(rows, nblk);
   nblk = cdiv(rows, rpb);
   dim3 grid((unsigned)cdiv(cols, (long)cx * VEC), (unsigned)nblk);

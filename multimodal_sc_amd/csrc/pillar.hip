@@ -7,7 +7,7 @@
 #include "msc_common.h"
 
 #define PIL_C 64
-#define PIL_BLOCKS 512
+#define PIL_BLOCKS 2048
 
 __device__ __forceinline__ int pillar_cell(float x, float y, float lo, float cell, int G) {
   const float fx = floorf((x - lo) / cell), fy = floorf((y - lo) / cell);
@@ -43,16 +43,37 @@ __global__ __launch_bounds__(256) void pillar_bwd_kernel(const float* __restrict
   const float w0 = w[lane * 4 + 0], w1 = w[lane * 4 + 1], w2 = w[lane * 4 + 2], w3 = w[lane * 4 + 3], bb = bias[lane];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
   const long nw = (long)gridDim.x * 4;
-  for (long p = (long)blockIdx.x * 4 + wave; p < npts_total; p += nw) {
-    const float4 pt = *reinterpret_cast<const float4*>(pts + p * 4);
-    const int c = pillar_cell(pt.x, pt.y, lo, cell, G);
-    if (c < 0) continue;
-    const float f = fmaf(w3, pt.w, fmaf(w2, pt.z, fmaf(w1, pt.y, w0 * pt.x))) + bb;
-    const long b = p / Np;
-    const long o = (b * G * G + c) * PIL_C + lane;
-    if (f > 0.f && f == grid[o]) {
-      const float g = msc_traits<T>::ld(dgrid + o);
-      a0 += g * pt.x; a1 += g * pt.y; a2 += g * pt.z; a3 += g * pt.w; a4 += g;
+  // 4 points per iteration: their dependent point -> cell -> grid/dgrid loads overlap instead of serialising
+  for (long p0 = ((long)blockIdx.x * 4 + wave) * 4; p0 < npts_total; p0 += nw * 4) {
+    float4 pt[4];
+    long o[4];
+    float f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long p = p0 + u;
+      o[u] = -1;
+      f[u] = 0.f;
+      if (p < npts_total) {
+        pt[u] = *reinterpret_cast<const float4*>(pts + p * 4);
+        const int c = pillar_cell(pt[u].x, pt[u].y, lo, cell, G);
+        if (c >= 0) {
+          f[u] = fmaf(w3, pt[u].w, fmaf(w2, pt[u].z, fmaf(w1, pt[u].y, w0 * pt[u].x))) + bb;
+          o[u] = ((p / Np) * G * G + c) * PIL_C + lane;
+        }
+      }
+    }
+    float gv[4], dg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gv[u] = o[u] >= 0 ? grid[o[u]] : -1.f;
+      dg[u] = o[u] >= 0 ? msc_traits<T>::ld(dgrid + o[u]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (f[u] > 0.f && f[u] == gv[u]) {
+        const float g = dg[u];
+        a0 += g * pt[u].x; a1 += g * pt[u].y; a2 += g * pt[u].z; a3 += g * pt[u].w; a4 += g;
+      }
     }
   }
   __shared__ float red[4][PIL_C][5];
@@ -65,10 +86,18 @@ __global__ __launch_bounds__(256) void pillar_bwd_kernel(const float* __restrict
 }
 
 __global__ void pillar_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PIL_C * 5) return;
+  // block = 32 outputs x 8 row lanes; lane r sums partial blocks r, r+8, ...; fixed-order combine (reproducible)
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += partial[(long)k * PIL_C * 5 + i];
+  if (i < PIL_C * 5)
+    for (int k = rl; k < nblk; k += 8) s += partial[(long)k * PIL_C * 5 + i];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl != 0 || i >= PIL_C * 5) return;
+  s = 0.f;
+  for (int r = 0; r < 8; ++r) s += red[r][cl];
   const int c = i / 5, j = i % 5;
   float* dst = j < 4 ? dw + c * 4 + j : db + c;
   *dst = (accumulate ? *dst : 0.f) + s;
@@ -115,7 +144,7 @@ extern "C" int msc_pillar_bwd(const float* points, const float* w, const float* 
   MSC_CHECK_ARG(points && w && bias && grid_f32 && dgrid && dw && db && ws && B > 0 && Np > 0 && G > 0 && C == PIL_C);
   hipStream_t st = (hipStream_t)stream;
   const long npts = (long)B * Np;
-  int blocks = cdiv(npts, 4 * 16);
+  int blocks = cdiv(npts, 4 * 4 * 8);
   if (blocks > PIL_BLOCKS) blocks = PIL_BLOCKS;
   if (dtype == MSC_F32)
     hipLaunchKernelGGL(pillar_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, points, w, bias, grid_f32, (const float*)dgrid, ws, npts, Np, G, range_lo, cell);
@@ -123,7 +152,7 @@ extern "C" int msc_pillar_bwd(const float* points, const float* w, const float* 
     hipLaunchKernelGGL(pillar_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, points, w, bias, grid_f32, (const bf16_t*)dgrid, ws, npts, Np, G, range_lo, cell);
   else
     return MSC_ERR_BAD_ARG;
-  hipLaunchKernelGGL(pillar_bwd_finalize_kernel, dim3(cdiv(PIL_C * 5, 64)), dim3(64), 0, st, ws, blocks, dw, db, accumulate);
+  hipLaunchKernelGGL(pillar_bwd_finalize_kernel, dim3(cdiv(PIL_C * 5, 32)), dim3(256), 0, st, ws, blocks, dw, db, accumulate);
   return msc_launch_status();
 }
 

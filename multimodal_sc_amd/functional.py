@@ -157,7 +157,7 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
     else:
         d = dy2d
     if b is not None:
-        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", N))
+        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N))
         rt.call("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
     wsw = rt.workspace("wgrad", wsb)
@@ -317,7 +317,7 @@ class TokensAssemble(torch.autograd.Function):
         d2 = rt.empty(B, n2, D) if n2 else None
         rt.call("msc_tokens_split", dout, d0, d1, d2, B, n0, n1, n2, D, rt.dt)
         cols = (n0 + n1 + n2) * D
-        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", cols))
+        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", B, cols))
         rt.call("msc_colsum", dout, pos.g, ws, B, cols, rt.accumulate, rt.dt)
         return d0, d1, d2, None, None
 

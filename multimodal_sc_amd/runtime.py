@@ -98,6 +98,7 @@ class ParamStore:
             r.c = self.C[sl].view(r.shape)
             r.t = self.TR[sl] if r.kind in ("conv", "linear") else None
         self.step_count = 0
+        self._ptable = None
 
     def __getitem__(self, name) -> ParamRef:
         return self.refs[name]
@@ -107,13 +108,21 @@ class ParamStore:
         rt = self.rt
         if cast and rt.dt != L.MSC_F32:
             rt.call("msc_cast", self.P, self.C, self.total, rt.dt)
-        for r in self.refs.values():
-            if r.kind == "conv":
-                co, kh, kw, ci = r.shape
-                rt.call("msc_permute3_cast", r.p, r.t, co, kh * kw, ci, rt.dt)
-            elif r.kind == "linear":
-                n, k = r.shape
-                rt.call("msc_permute3_cast", r.p, r.t, n, 1, k, rt.dt)
+        if self._ptable is None:
+            # descriptor table of every weight transpose: one launch per step instead of one per weight
+            rows, blk = [], 0
+            for r in self.refs.values():
+                if r.kind == "conv":
+                    d0, d1, d2 = r.shape[0], r.shape[1] * r.shape[2], r.shape[3]
+                elif r.kind == "linear":
+                    d0, d1, d2 = r.shape[0], 1, r.shape[1]
+                else:
+                    continue
+                rows.append([r.off, r.off, d0, d1, d2, blk])
+                blk += ((d2 + 31) // 32) * ((d0 + 31) // 32) * d1
+            self._ptable = torch.tensor(rows, dtype=torch.int64, device=rt.device)
+            self._pblocks = blk
+        rt.call("msc_permute3_cast_batched", self.P, self.TR, self._ptable, self._ptable.shape[0], self._pblocks, rt.dt)
 
     def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         rt = self.rt
