@@ -80,6 +80,17 @@ int msc_gemm_batched(const void* A, const void* Bm, void* C, int M, int N, int K
                      int c_f32, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FusionTransformer: fused (flash-style) multi-head attention, head_dim 64, bf16 (MSC_ERR_UNSUPPORTED otherwise —
+ * the exact-fp32 parity mode uses msc_gemm_batched + msc_softmax_*).  qkv: [B*T][3*H*64] (q | k | v, heads inside),
+ * o: [B*T][H*64], lse: fp32 [B*H][msc_attention_tpad(T)] (log2-domain log-sum-exp, saved for the backward),
+ * delta: fp32 scratch of the same shape, dqkv: [B*T][3*H*64].  No score matrix is written to HBM. */
+int64_t msc_attention_tpad(int T);
+int msc_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int hd, float scale, int dtype,
+                      void* stream);
+int msc_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                      int B, int T, int H, int hd, float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * BatchNorm (training-mode batch statistics, per-GPU under DP) and LayerNorm.
  * msc_bn_finalize: mean/rstd [C] from the conv epilogue partials (fp64 combine, fixed order) and the folded
  *                  per-channel affine scale = gamma*rstd, shift = beta - mean*scale used by msc_bn_apply.

@@ -219,10 +219,20 @@ class LayerNorm(torch.autograd.Function):
         return dx.view(shp), None, None, None
 
 
-# ------------------------------------------------------------------------------------------------ attention (unfused v1)
+# ------------------------------------------------------------------------------------------------ attention
+def fused_attention_ok(rt: Runtime, T, hd):
+    """the flash-style kernel covers bf16, head_dim 64, T <= 512; the exact-fp32 parity mode takes the GEMM+softmax path"""
+    return rt.dt == L.MSC_BF16 and hd == 64 and T <= 512 and rt.fused_attention
+
+
 def attention_fwd(rt: Runtime, qkv, B, T, h, hd):
-    """qkv: [B*T, 3*h*hd] (q|k|v, heads inside). -> o [B*T, h*hd], P [B*h, T, Tp]"""
+    """qkv: [B*T, 3*h*hd] (q|k|v, heads inside). -> o [B*T, h*hd], aux (lse [B*h,Tpad] fused | P [B*h,T,Tp] unfused)"""
     D = h * hd
+    if fused_attention_ok(rt, T, hd):
+        o = rt.empty(B * T, D)
+        lse = rt.f32(B * h, L.query("msc_attention_tpad", T))
+        rt.call("msc_attention_fwd", qkv, o, lse, B, T, h, hd, 1.0 / math.sqrt(hd), rt.dt)
+        return o, lse
     Tp = _cdiv(T, 64) * 64
     S = rt.workspace("attn_scores", B * h * T * Tp * 4)
     q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
@@ -238,8 +248,14 @@ def attention_fwd(rt: Runtime, qkv, B, T, h, hd):
     return o, P
 
 
-def attention_bwd(rt: Runtime, do, qkv, P, B, T, h, hd):
+def attention_bwd(rt: Runtime, do, qkv, o, P, B, T, h, hd):
     D = h * hd
+    if fused_attention_ok(rt, T, hd):
+        lse = P
+        dqkv = rt.empty(B * T, 3 * D)
+        delta = rt.workspace("attn_delta", lse.numel() * 4)
+        rt.call("msc_attention_bwd", qkv, o, do, lse, delta, dqkv, B, T, h, hd, 1.0 / math.sqrt(hd), rt.dt)
+        return dqkv
     Tp = P.shape[-1]
     ld = 3 * D
     q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
@@ -290,7 +306,7 @@ class FusionLayerFn(torch.autograd.Function):
         dh2 = linear_bwd(rt, du, h2, upre, p["fc1w"], p["fc1b"], L.ACT_GELU)
         dx1 = layernorm_bwd(rt, dh2, x1, mu2, rs2, p["ln2g"], p["ln2b"], dadd=dx2)       # + residual branch
         do = linear_bwd(rt, dx1, o, None, p["projw"], p["projb"], L.ACT_NONE)
-        dqkv = attention_bwd(rt, do, qkv, P, B, T, h, hd)
+        dqkv = attention_bwd(rt, do, qkv, o, P, B, T, h, hd)
         dh1 = linear_bwd(rt, dqkv, h1, None, p["qkvw"], p["qkvb"], L.ACT_NONE)
         dx = layernorm_bwd(rt, dh1, x2d, mu1, rs1, p["ln1g"], p["ln1b"], dadd=dx1)
         return dx.view(B, T, D), None, None, None

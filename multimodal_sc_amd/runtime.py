@@ -38,6 +38,7 @@ class Runtime:
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
+        self.fused_attention = True  # bf16: flash-style kernel; False forces the batched-GEMM + softmax path (tests)
         L.lib.load()                # fail loudly, now, if the HIP extension is missing
 
     @property
