@@ -45,13 +45,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define DMA_OOB 0x80000000u   // >= num_records of every descriptor built here: the DMA writes zeros
+#ifndef GEMM_STAGES
+#define GEMM_STAGES 3         // LDS buffers of the DMA pipeline (STAGES-1 K steps in flight)
+#endif
 
 template <int MODE> struct mode_is_kmajor { static constexpr bool value = (MODE == OPM_DENSE_K || MODE == OPM_CONV_FWD || MODE == OPM_CONV_DGRAD); };
 
 __device__ __forceinline__ int lds_chunk_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 // swizzle of the 16-byte chunk index inside an mn-major LDS row of ROWB bytes, keyed by the k row
 template <int ROWB> __device__ __forceinline__ int mn_swz(int krow) {
-  return ROWB == 256 ? ((krow & 3) << 2) : (((krow >> 1) & 1) << 2);
+  return ROWB >= 256 ? ((krow & 3) << 2) : (((krow >> 1) & 1) << 2);
 }
 
 // One K step of the schedule: kbase = first reduction index of the step; (kh, kw, co0) = its filter tap and first
@@ -80,12 +83,12 @@ __device__ __forceinline__ void dgrad_row_to_pixel(const GemmParams& p, int row,
 // ------------------------------------------------------------------------------------------------
 // Operand loader.  DMA = true: LDS-DMA path (k-major any dtype; mn-major bf16).  DMA = false: registers + transposing
 // LDS write (mn-major fp32 only).
-template <typename T, int MODE, int ROWS> struct OperandLoader {
+template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
   static constexpr bool KM = mode_is_kmajor<MODE>::value;
   static constexpr bool DMA = KM || sizeof(T) == 2;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int KT = 64 / sizeof(T);
-  static constexpr int NCH = ROWS * 4 / 256;                   // 16-byte chunks per thread per K step
+  static constexpr int NCH = ROWS * 4 / NTHR;                  // 16-byte chunks per thread per K step
   static constexpr int ROWB = KM ? 64 : ROWS * (int)sizeof(T); // LDS row bytes
   static constexpr int CPR = ROWB / 16;                        // chunks per LDS row (DMA) / per reduction row (REG)
   static constexpr int RPI = 1024 / ROWB;                      // LDS rows written by one DMA wave-instruction
@@ -113,7 +116,7 @@ template <typename T, int MODE, int ROWS> struct OperandLoader {
         c = (lane % CPR) ^ mn_swz<ROWB>(r);        // logical chunk along the mn axis
       }
     } else {
-      const int id = tid + i * 256;
+      const int id = tid + i * NTHR;
       r = id / CPR;
       c = id % CPR;
     }
@@ -262,14 +265,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int AMODE, int BMODE, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm_kernel(const GemmParams p) {
+  constexpr int NTHR = BM == 256 ? 512 : 256;   // 8 waves (4x2) for the 256-row tile, 4 waves (2x2) otherwise
   constexpr int KT = 64 / sizeof(T);
-  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+  constexpr int NWM = BM == 256 ? 4 : 2;        // waves along M
+  constexpr int WM = BM / NWM, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
   constexpr int EP_BYTES = 64 * BN * 4;     // epilogue slab: 64 rows x BN fp32
-  constexpr int SMEM_BYTES = 2 * (A_BYTES + B_BYTES) > EP_BYTES ? 2 * (A_BYTES + B_BYTES) : EP_BYTES;
-  using LA = OperandLoader<T, AMODE, BM>;
-  using LB = OperandLoader<T, BMODE, BN>;
+  using LA = OperandLoader<T, AMODE, BM, NTHR>;
+  using LB = OperandLoader<T, BMODE, BN, NTHR>;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int STAGES = (LA::DMA && LB::DMA) ? GEMM_STAGES : 2;
+  constexpr int SMEM_BYTES = STAGES * STAGE_BYTES > EP_BYTES ? STAGES * STAGE_BYTES : EP_BYTES;
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,25 +347,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
   uint4 ra[LA::NCH], rb[LB::NCH];
 
-  if (nk > 0) {
-    if constexpr (LA::DMA) la.issue(p, p.K, smem, ks); else { la.load(p, p.K, ra, ks); la.store(smem, ra); }
-    if constexpr (LB::DMA) lb.issue(p, p.K, smem + A_BYTES, ks); else { lb.load(p, p.K, rb, ks); lb.store(smem + A_BYTES, rb); }
-    advance();
+  // Software pipeline: STAGES LDS buffers, STAGES-1 K steps of LDS-DMA in flight.  Every wave waits for its own DMA
+  // instructions of the step it is about to read with a COUNTED vmcnt (the younger steps stay in flight across the
+  // barrier), then a raw s_barrier makes every wave's part visible (cdna_hip_programming.md "Pipelining across barriers").
+  constexpr int NPS = LA::NCH + LB::NCH;              // DMA wave-instructions per K step
+  constexpr int WAIT_N = NPS * (STAGES - 2);          // instructions of the younger in-flight steps
+  int issued = 0;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) {
+    if (issued < nk) {
+      char* buf = smem + s * STAGE_BYTES;
+      if constexpr (LA::DMA) la.issue(p, p.K, buf, ks); else { la.load(p, p.K, ra, ks); la.store(buf, ra); }
+      if constexpr (LB::DMA) lb.issue(p, p.K, buf + A_BYTES, ks); else { lb.load(p, p.K, rb, ks); lb.store(buf + A_BYTES, rb); }
+      advance();
+      ++issued;
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (issued == STAGES - 1 && STAGES > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_N) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
   const int lr = lane & 31, lh = lane >> 5;
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    char* nxt = smem + (cur ^ 1) * (A_BYTES + B_BYTES);
+    const bool more = issued < nk;
+    int nb = cur + (STAGES - 1);
+    if (nb >= STAGES) nb -= STAGES;
+    char* nxt = smem + nb * STAGE_BYTES;
     if (more) {
       if constexpr (LA::DMA) la.issue(p, p.K, nxt, ks); else la.load(p, p.K, ra, ks);
       if constexpr (LB::DMA) lb.issue(p, p.K, nxt + A_BYTES, ks); else lb.load(p, p.K, rb, ks);
       advance();
+      ++issued;
     }
-    const char* As = smem + cur * (A_BYTES + B_BYTES);
+    const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + A_BYTES;
     if constexpr (sizeof(T) == 2) {
       // lane geometry of the transposed read (mn-major images): 16-lane group g, row q / column quad pq inside it
@@ -426,15 +449,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       if constexpr (!LA::DMA) la.store(nxt, ra);
       if constexpr (!LB::DMA) lb.store(nxt + A_BYTES, rb);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of step t+1 has landed (this wave's part) ...
-    __syncthreads();                                    // ... and so has everyone else's
-    cur ^= 1;
+    // step kt+1 must have landed (this wave's part); steps kt+2.. may stay in flight when the pipe is full
+    if (STAGES > 2 && issued - (kt + 2) == STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads of this buffer are done before it is refilled
+    __builtin_amdgcn_s_barrier();                        // ... and every other wave's DMA part is visible
+    asm volatile("" ::: "memory");                       // keep the next step's LDS traffic below the barrier
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
+  __syncthreads();
 
   // ---------------------------------------------------------------- epilogue
   // (1) BatchNorm partial statistics straight from the fp32 accumulators (conv forward only)
   if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [2 wm][2 stat][BN]
+    float* red = reinterpret_cast<float*>(smem);  // [NWM][2 stat][BN]
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       float s1 = 0.f, s2 = 0.f;
@@ -453,8 +481,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) {
       float* st = p.stats + (long)tile_m * 2 * p.N;
-      st[n0 + tid] = red[(0 * 2 + 0) * BN + tid] + red[(1 * 2 + 0) * BN + tid];
-      st[p.N + n0 + tid] = red[(0 * 2 + 1) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWM; ++w) { a1 += red[(w * 2 + 0) * BN + tid]; a2 += red[(w * 2 + 1) * BN + tid]; }
+      st[n0 + tid] = a1;
+      st[p.N + n0 + tid] = a2;
     }
     __syncthreads();
   }
@@ -483,8 +514,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     if (f32out) {
       constexpr int CPRW = BN / 4;
 #pragma unroll
-      for (int it = 0; it < 64 * CPRW / 256; ++it) {
-        const int id = tid + it * 256;
+      for (int it = 0; it < 64 * CPRW / NTHR; ++it) {
+        const int id = tid + it * NTHR;
         const int row = id / CPRW, cc = id % CPRW;
         const int m = m0 + ps * 64 + row, n = n0 + cc * 4;
         if (m >= p.M || n >= p.N) continue;
@@ -503,8 +534,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       T* C2 = reinterpret_cast<T*>(p.C2);
       const T* Rs = reinterpret_cast<const T*>(p.res);
 #pragma unroll
-      for (int it = 0; it < 64 * CPRW / 256; ++it) {
-        const int id = tid + it * 256;
+      for (int it = 0; it < 64 * CPRW / NTHR; ++it) {
+        const int id = tid + it * NTHR;
         const int row = id / CPRW, cc = id % CPRW;
         const int m = m0 + ps * 64 + row, n = n0 + cc * VEC;
         if (m >= p.M || n >= p.N) continue;
@@ -581,9 +612,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
 // ------------------------------------------------------------------------------------------------
 // tile choice: narrow operands get 64-wide tiles; launches that would leave most of the 256 CUs idle trade MFMA work
 // per LDS byte for more workgroups
-static void choose_tile(long M, long N, long zs, int& bm, int& bn) {
+static void choose_tile(long M, long N, long zs, int& bm, int& bn, bool allow256 = true) {
   bm = M <= 64 ? 64 : 128;
   bn = N <= 64 ? 64 : 128;
+  // 256x128 tiles (8 waves) raise the FLOPs per byte staged into LDS from 64 to 85; used when they still fill the chip
+  if (allow256 && bn == 128 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 128) * zs >= 256) { bm = 256; return; }
   if (bn == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bn = 64;
   if (bm == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bm = 64;
 }
@@ -599,9 +632,10 @@ template <typename T, int AMODE, int BMODE>
 static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   int bm, bn;
   const long zs = (long)batch * p.nsplit;
-  choose_tile(p.M, p.N, zs, bm, bn);
+  choose_tile(p.M, p.N, zs, bm, bn, mode_is_kmajor<AMODE>::value);   // 256-row tiles only for k-major A operands
   dim3 grid((unsigned)(cdiv(p.M, bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128>), grid, dim3(256), 0, st, p);
+  if (bm == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128>), grid, dim3(512), 0, st, p);
+  else if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128>), grid, dim3(256), 0, st, p);
   else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64>), grid, dim3(256), 0, st, p);
   else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64>), grid, dim3(256), 0, st, p);

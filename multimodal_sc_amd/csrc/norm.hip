@@ -27,7 +27,17 @@ __global__ __launch_bounds__(256) void finalize2_kernel(const FinArgs a) {
   const int c = blockIdx.x * 8 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < a.C) {
-    for (int b = rl; b < a.nblk; b += 32) {
+    // 4 independent load pairs per trip: the serial part is the fp64 add chain, not a chain of memory round trips
+    int b = rl;
+    for (; b + 96 < a.nblk; b += 128) {
+      const float x0 = a.partial[(long)b * 2 * a.C + c], y0 = a.partial[(long)b * 2 * a.C + a.C + c];
+      const float x1 = a.partial[(long)(b + 32) * 2 * a.C + c], y1 = a.partial[(long)(b + 32) * 2 * a.C + a.C + c];
+      const float x2 = a.partial[(long)(b + 64) * 2 * a.C + c], y2 = a.partial[(long)(b + 64) * 2 * a.C + a.C + c];
+      const float x3 = a.partial[(long)(b + 96) * 2 * a.C + c], y3 = a.partial[(long)(b + 96) * 2 * a.C + a.C + c];
+      s1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+      s2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+    }
+    for (; b < a.nblk; b += 32) {
       s1 += (double)a.partial[(long)b * 2 * a.C + c];
       s2 += (double)a.partial[(long)b * 2 * a.C + a.C + c];
     }
@@ -357,8 +367,15 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nb
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;     // 32 columns x 8 row lanes
   const long c = (long)blockIdx.x * 32 + cl;
   float s = 0.f;
-  if (c < C)
-    for (int k = rl; k < nblk; k += 8) s += partial[(long)k * C + c];
+  if (c < C) {
+    int k = rl;
+    for (; k + 24 < nblk; k += 32) {   // 4 independent loads per trip
+      const float x0 = partial[(long)k * C + c], x1 = partial[(long)(k + 8) * C + c];
+      const float x2 = partial[(long)(k + 16) * C + c], x3 = partial[(long)(k + 24) * C + c];
+      s += (x0 + x1) + (x2 + x3);
+    }
+    for (; k < nblk; k += 8) s += partial[(long)k * C + c];
+  }
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < C) {
