@@ -93,11 +93,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # MSC_BENCH_BACKEND=gloo rehearses the N>1 code path on a one-GPU box (all ranks share cuda:0, gradients summed
+    # through host memory); the driver's real runs use the default "nccl" = RCCL, one rank per GPU.
+    backend = os.environ.get("MSC_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     cfg = named_config(args.config)
     model = MultimodalSC(cfg, dtype=args.dtype, device=dev, seed=0)
@@ -139,6 +146,13 @@ def main():
                    "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "frames_per_s_per_gpu": B * args.steps / dt, "psnr_db": met["psnr"], "loss": met["loss"],
     }
+    if world > 1:
+        # data-parallel sanity (outside the timed region): every rank must hold bit-identical parameters
+        chk = model.params.P.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        result["dp_params_in_sync"] = bool((lo == hi).item())
 
     if rank == 0 and not args.no_roofline:
         rt = model.rt

@@ -335,6 +335,10 @@ class TokensAssemble(torch.autograd.Function):
         cols = (n0 + n1 + n2) * D
         ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", B, cols))
         rt.call("msc_colsum", dout, pos.g, ws, B, cols, rt.accumulate, rt.dt)
+        # every gradient from fusion.pos_embed to the end of the flat buffer (transformer, codec, heads) is final now;
+        # the trainer uses this point to start their all-reduce under the encoder backward that follows
+        if rt.on_upper_grads_ready is not None:
+            rt.on_upper_grads_ready()
         return d0, d1, d2, None, None
 
 

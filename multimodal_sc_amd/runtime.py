@@ -39,6 +39,7 @@ class Runtime:
         self._ws = {}
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
         self.fused_attention = True  # bf16: flash-style kernel; False forces the batched-GEMM + softmax path (tests)
+        self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
         L.lib.load()                # fail loudly, now, if the HIP extension is missing
 
     @property

@@ -1,11 +1,19 @@
 """Trainer.step: forward -> fused losses -> kernel backward chain -> DP gradient all-reduce (RCCL) -> fused Adam.
 
 Data parallelism: one process per GPU, frames sharded over ranks (BatchNorm statistics stay per-GPU).  The only
-exchange step of the path is the gradient sum: the flat fp32 gradient buffer is all-reduced in a few large buckets
-with torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests), issued on a side stream
-so that later buckets overlap the optimizer work of earlier ones.
+exchange step of the path is the gradient sum over the flat fp32 gradient buffer G, done with torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests) in two large pieces so that most of it hides
+under compute:
+  upper  G[fusion.pos_embed:]  (transformer, semantic codec, heads: ~56 MB) — final as soon as the backward leaves
+         the fusion transformer; its all-reduce is enqueued from inside the backward (Runtime.on_upper_grads_ready)
+         and runs on RCCL's stream under the whole encoder (ResNet-18 + BEV) backward that follows;
+  lower  G[:fusion.pos_embed]  (image / BEV / state encoders: ~52 MB) — reduced after the backward.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): few, large messages let RCCL drive all links; small buckets
+would be latency-bound per link.  MSC_DP_OVERLAP=0 falls back to one non-overlapped bucketed all-reduce.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -41,6 +49,8 @@ class Trainer:
         self.n_buckets = n_buckets
         self.use_ppo = use_ppo
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
+        self.split = model.params.refs["fusion.pos_embed"].off
 
     def forward_backward(self, batch):
         m = self.model
@@ -51,9 +61,22 @@ class Trainer:
     def step(self, batch):
         """One optimisation step on this rank's shard of the batch; returns the (device-side) loss terms."""
         m = self.model
-        _, terms = self.forward_backward(batch)
+        G = m.params.G
+        works = []
+        if self.world > 1 and self.overlap:
+            def upper_ready():
+                works.append(dist.all_reduce(G[self.split:], op=dist.ReduceOp.SUM, async_op=True))
+            m.rt.on_upper_grads_ready = upper_ready
+        try:
+            _, terms = self.forward_backward(batch)
+        finally:
+            m.rt.on_upper_grads_ready = None
         if self.world > 1:
-            for w in allreduce_flat(m.params.G, self.n_buckets):
+            if works:
+                works.append(dist.all_reduce(G[: self.split], op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                works = allreduce_flat(G, self.n_buckets)
+            for w in works:
                 w.wait()
         m.params.adam_step(lr=self.lr, grad_scale=1.0 / self.world)
         return terms
