@@ -35,8 +35,10 @@ def gemm_flops(name, s):
         return conv(*s[:9])
     if name == "msc_conv2d_wgrad":
         return conv(*s[1:10])
-    if name in ("msc_linear_fwd", "msc_linear_dgrad"):
+    if name == "msc_linear_fwd":
         return 2.0 * s[0] * s[1] * s[2]
+    if name == "msc_linear_dgrad":      # scalars: dact, M, N, K, dtype
+        return 2.0 * s[1] * s[2] * s[3]
     if name == "msc_linear_wgrad":
         return 2.0 * s[1] * s[2] * s[3]
     if name == "msc_gemm_batched":

@@ -61,8 +61,15 @@ int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_
  * pre-activation (needed by GELU/tanh backward).  bias,res,pre optional.  bias is fp32. */
 int msc_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, void* pre,
                    int M, int N, int K, int act, int dtype, void* stream);
-/* dx[M,K] = dy[M,N] wt[K,N]^T  (wt = w transposed, [K][N] row-major) */
-int msc_linear_dgrad(const void* dy, const void* wt, void* dx, int M, int N, int K, int dtype, void* stream);
+/* dx[M,K] = (dy[M,N] wt[K,N]^T) * act'(dact_ref[M,K])   (wt = w transposed, [K][N] row-major).
+ * dact_ref/dact (optional): fused backward of the activation that FED this layer — dact_ref is that activation's
+ * output (relu/tanh/sigmoid) or pre-activation (gelu); dx is then the gradient w.r.t. the previous layer's
+ * pre-activation.  colsum_partial (optional): fp32 [msc_linear_dgrad_colsum_rows(M,K)][K] per-row-block column sums
+ * of dx (= the previous layer's bias gradient after msc_colsum_finalize). */
+int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K);
+int msc_linear_dgrad(const void* dy, const void* wt, const void* dact_ref, int dact, float* colsum_partial, void* dx,
+                     int M, int N, int K, int dtype, void* stream);
+int msc_colsum_finalize(const float* partial, int nblk, int64_t cols, float* out, int accumulate, void* stream);
 /* dw[N,K] (fp32) = dy[M,N]^T x[M,K] */
 int msc_linear_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int M, int N,
                      int K, int accumulate, int dtype, void* stream);

@@ -39,6 +39,8 @@ struct GemmParams {
   // geometry of the gathered NHWC tensor (conv modes)
   int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
   int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
+  const void* dref; int dact;   // epilogue: multiply by act'(dref[m][n]) (fused activation backward)
+  float* colsum;                // epilogue: per-row-block column sums of the stored output, [tile_m][N]
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
@@ -264,7 +266,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int AMODE, int BMODE, int BM, int BN>
+// EPX: extended epilogue (fused activation backward + column sums) — compiled only into the kernels that use it so the
+// common epilogue keeps its register budget.
+template <typename T, int AMODE, int BMODE, int BM, int BN, bool EPX = false>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm_kernel(const GemmParams p) {
   constexpr int NTHR = BM == 256 ? 512 : 256;   // 8 waves (4x2) for the 256-row tile, 4 waves (2x2) otherwise
   constexpr int KT = 64 / sizeof(T);
@@ -497,6 +501,9 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
   char* Cbase = f32out ? reinterpret_cast<char*>(reinterpret_cast<float*>(p.C) + (p.nsplit > 1 ? (long)split * p.M * p.ldc : (zo * p.sc_o + zi * p.sc_i)))
                        : reinterpret_cast<char*>(reinterpret_cast<T*>(p.C) + zo * p.sc_o + zi * p.sc_i);
   constexpr int PASSES = BM / 64;
+  float csum[16 / sizeof(T)];   // this thread's column chunk is the same in every iteration (NTHR % (BN/VEC) == 0)
+#pragma unroll
+  for (int e = 0; e < (int)(16 / sizeof(T)); ++e) csum[e] = 0.f;
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
     const bool mine = (PASSES == 1) || (wm == ps);
@@ -579,6 +586,18 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] += vr.v[e];
           }
+          if constexpr (EPX) {
+            if (p.dref) {   // fused activation backward: gradient w.r.t. the pre-activation
+              vecf<T> vr;
+              vr.load(reinterpret_cast<const T*>(p.dref) + o);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) v[e] *= act_grad(vr.v[e], p.dact);
+            }
+            if (p.colsum) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) csum[e] += v[e];
+            }
+          }
 #pragma unroll
           for (int e = 0; e < VEC; ++e) vo.v[e] = v[e];
           vo.store(dst);
@@ -588,12 +607,31 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
             if (C2) msc_traits<T>::st(C2 + o + e, x);
             x = act_apply(x, p.act);
             if (Rs) x += msc_traits<T>::ld(Rs + o + e);
+            if constexpr (EPX) {
+              if (p.dref) x *= act_grad(msc_traits<T>::ld(reinterpret_cast<const T*>(p.dref) + o + e), p.dact);
+              if (p.colsum) csum[e] += x;
+            }
             msc_traits<T>::st(dst + e, x);
           }
         }
       }
     }
     if (ps + 1 < PASSES) __syncthreads();
+  }
+  if (EPX && p.colsum && !f32out) {
+    // fixed-order reduction of the per-thread column sums over the NTHR/(BN/VEC) threads that share a column chunk
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int CPRW = BN / VEC, NR = NTHR / CPRW;
+    __syncthreads();
+    const int cc = tid % CPRW, rr = tid / CPRW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) slab[rr * BN + cc * VEC + e] = csum[e];
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float a = 0.f;
+      for (int r = 0; r < NR; ++r) a += slab[r * BN + tid];
+      p.colsum[(long)tile_m * p.N + n0 + tid] = a;
+    }
   }
 }
 
@@ -628,24 +666,24 @@ extern "C" int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout) {
   return cdiv(rows, bm);
 }
 
-template <typename T, int AMODE, int BMODE>
+template <typename T, int AMODE, int BMODE, bool EPX = false>
 static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   int bm, bn;
   const long zs = (long)batch * p.nsplit;
-  choose_tile(p.M, p.N, zs, bm, bn, mode_is_kmajor<AMODE>::value);   // 256-row tiles only for k-major A operands
+  choose_tile(p.M, p.N, zs, bm, bn, mode_is_kmajor<AMODE>::value && !EPX);   // 256-row tiles: k-major A, plain epilogue
   dim3 grid((unsigned)(cdiv(p.M, bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
-  if (bm == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128>), grid, dim3(512), 0, st, p);
-  else if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128>), grid, dim3(256), 0, st, p);
-  else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64>), grid, dim3(256), 0, st, p);
-  else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64>), grid, dim3(256), 0, st, p);
+  if (bm == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX>), grid, dim3(512), 0, st, p);
+  else if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX>), grid, dim3(256), 0, st, p);
+  else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64, EPX>), grid, dim3(256), 0, st, p);
+  else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128, EPX>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64, EPX>), grid, dim3(256), 0, st, p);
   return msc_launch_status();
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, bool EPX = false>
 static int launch_gemm_dt(const GemmParams& p, int batch, int dtype, hipStream_t st) {
-  if (dtype == MSC_F32) return launch_gemm<float, AMODE, BMODE>(p, batch, st);
-  if (dtype == MSC_BF16) return launch_gemm<bf16_t, AMODE, BMODE>(p, batch, st);
+  if (dtype == MSC_F32) return launch_gemm<float, AMODE, BMODE, EPX>(p, batch, st);
+  if (dtype == MSC_BF16) return launch_gemm<bf16_t, AMODE, BMODE, EPX>(p, batch, st);
   return MSC_ERR_BAD_ARG;
 }
 
@@ -780,14 +818,23 @@ extern "C" int msc_linear_fwd(const void* x, const void* w, const float* bias, c
   return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
 }
 
-extern "C" int msc_linear_dgrad(const void* dy, const void* wt, void* dx, int M, int N, int K, int dtype, void* stream) {
+// rows of the column-sum partial buffer msc_linear_dgrad writes for an [M][K] output
+extern "C" int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K) {
+  int bm, bn;
+  choose_tile(M, K, 1, bm, bn, false);   // the extended-epilogue kernels never use the 256-row tile
+  return cdiv(M, bm);
+}
+
+extern "C" int msc_linear_dgrad(const void* dy, const void* wt, const void* dact_ref, int dact, float* colsum_partial, void* dx, int M,
+                                int N, int K, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && wt && dx && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(N % vec_of(dtype) == 0);
   if (!fits32((long)M * N, dtype) || !fits32((long)N * K, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
-  p.A = dy; p.B = wt; p.C = dx;
+  p.A = dy; p.B = wt; p.C = dx; p.dref = dact_ref; p.dact = dact; p.colsum = colsum_partial;
   p.M = M; p.N = K; p.K = N; p.lda = N; p.ldb = N; p.ldc = K;
+  if (dact_ref || colsum_partial) return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K, true>(p, 1, dtype, (hipStream_t)stream);
   return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
 }
 

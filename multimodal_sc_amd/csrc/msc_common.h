@@ -113,6 +113,17 @@ __device__ __forceinline__ float act_apply(float x, int act) {
   }
 }
 
+// d act(x)/dx given ref = output y (relu/tanh/sigmoid) or the pre-activation x (gelu)
+__device__ __forceinline__ float act_grad(float r, int act) {
+  switch (act) {
+    case MSC_ACT_RELU: return r > 0.f ? 1.f : 0.f;
+    case MSC_ACT_TANH: return 1.f - r * r;
+    case MSC_ACT_SIGMOID: return r * (1.f - r);
+    case MSC_ACT_GELU: return 0.5f * (1.f + fast_erf(r * 0.70710678118654752f)) + r * 0.3989422804014327f * __expf(-0.5f * r * r);
+    default: return 1.f;
+  }
+}
+
 static inline int ilog2_exact(int v) {  // -1 when v is not a power of two
   if (v <= 0 || (v & (v - 1))) return -1;
   int l = 0;

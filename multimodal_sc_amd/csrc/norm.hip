@@ -518,6 +518,14 @@ static int colsum_row_blocks(long rows) {
   return (int)nblk;
 }
 
+// out[c] (+)= sum_k partial[k][c] — finish column sums whose per-row-block partials another kernel produced
+// (msc_linear_dgrad's fused bias-gradient epilogue)
+extern "C" int msc_colsum_finalize(const float* partial, int nblk, int64_t cols, float* out, int accumulate, void* stream) {
+  MSC_CHECK_ARG(partial && out && nblk > 0 && cols > 0);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, (long)cols, out, accumulate);
+  return msc_launch_status();
+}
+
 extern "C" int64_t msc_colsum_workspace_bytes(int64_t rows, int64_t cols) {
   return (int64_t)colsum_row_blocks(rows) * cols * 4;
 }

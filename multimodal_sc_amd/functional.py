@@ -147,8 +147,12 @@ def linear_fwd(rt: Runtime, x2d, w: ParamRef, b: ParamRef, act=L.ACT_NONE, res=N
     return y, pre
 
 
-def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_dx=True):
-    """dy2d: gradient w.r.t. the layer output (after activation). ref: y (relu/tanh/sigmoid) or pre (gelu)."""
+def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_dx=True, bias_done=False,
+               prev_act=L.ACT_NONE, prev_ref=None, prev_bias: ParamRef = None):
+    """dy2d: gradient w.r.t. the layer output (after activation). ref: y (relu/tanh/sigmoid) or pre (gelu).
+    prev_act/prev_ref/prev_bias: fuse the backward of the activation that FED this layer (and the bias gradient of the
+    layer that produced it) into the dgrad epilogue — the returned dx is then the gradient w.r.t. that pre-activation
+    and prev_bias.g is filled; the caller passes act=ACT_NONE, bias_done=True to the previous layer's linear_bwd."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     if act != L.ACT_NONE:
@@ -156,7 +160,7 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
         rt.call("msc_act_bwd", dy2d, ref, d, M * N, act, rt.dt)
     else:
         d = dy2d
-    if b is not None:
+    if b is not None and not bias_done:
         ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N))
         rt.call("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
@@ -165,7 +169,13 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
     dx = None
     if need_dx:
         dx = rt.empty(M, K)
-        rt.call("msc_linear_dgrad", d, w.t, dx, M, N, K, rt.dt)
+        part = None
+        if prev_bias is not None:
+            nblk = L.query("msc_linear_dgrad_colsum_rows", M, K)
+            part = rt.workspace("dgrad_colsum", nblk * K * 4)
+        rt.call("msc_linear_dgrad", d, w.t, prev_ref, prev_act, part, dx, M, N, K, rt.dt)
+        if prev_bias is not None:
+            rt.call("msc_colsum_finalize", part, nblk, K, prev_bias.g, rt.accumulate)
     return dx
 
 
@@ -302,8 +312,10 @@ class FusionLayerFn(torch.autograd.Function):
         hd = D // h
         x2d, mu1, rs1, h1, qkv, P, o, x1, mu2, rs2, h2, upre, u = ctx.saved_tensors
         dx2 = dy.reshape(B * T, D).contiguous()
-        du = linear_bwd(rt, dx2, u, None, p["fc2w"], p["fc2b"], L.ACT_NONE)
-        dh2 = linear_bwd(rt, du, h2, upre, p["fc1w"], p["fc1b"], L.ACT_GELU)
+        # fc2's dgrad epilogue applies GELU' (from the saved pre-activation) and emits fc1's bias gradient
+        dpre = linear_bwd(rt, dx2, u, None, p["fc2w"], p["fc2b"], L.ACT_NONE, prev_act=L.ACT_GELU, prev_ref=upre,
+                          prev_bias=p["fc1b"])
+        dh2 = linear_bwd(rt, dpre, h2, None, p["fc1w"], p["fc1b"], L.ACT_NONE, bias_done=True)
         dx1 = layernorm_bwd(rt, dh2, x1, mu2, rs2, p["ln2g"], p["ln2b"], dadd=dx2)       # + residual branch
         do = linear_bwd(rt, dx1, o, None, p["projw"], p["projb"], L.ACT_NONE)
         dqkv = attention_bwd(rt, do, qkv, o, P, B, T, h, hd)

@@ -120,6 +120,28 @@ def test_linear_fwd_bwd(rts, dtype, M, N, K, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,act", [(300, 128, 256, 2), (1000, 512, 2048, 2), (70, 64, 64, 1)])
+def test_linear_dgrad_fused_act_and_bias(rts, dtype, M, N, K, act):
+    """dgrad epilogue: dx = (dy W) * act'(ref) and the per-row-block column sums that become the previous bias gradient"""
+    from multimodal_sc_amd import lib as L
+    rt = rts[dtype]
+    dy, w, pre = rnd(M, N, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(N)), rnd(M, K, seed=3)
+    pq = q(pre, dtype).requires_grad_()
+    y = TF.gelu(pq) if act == 2 else torch.relu(pq)
+    ref_in = pq if act == 2 else y                      # gelu: pre-activation, relu: output
+    (y @ q(w, dtype).t()).backward(q(dy, dtype))
+    Wp = FakeParam(rt, w, "linear")
+    dx = rt.empty(M, K)
+    nblk = L.query("msc_linear_dgrad_colsum_rows", M, K)
+    part = torch.full((nblk, K), float("nan"), device=rt.device)
+    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, dev(ref_in.detach(), rt), act, part, dx, M, N, K, rt.dt)
+    check("dx", dx, pq.grad, tol(dtype) * 2)
+    db = torch.empty(K, device=rt.device)
+    rt.call("msc_colsum_finalize", part, nblk, K, db, 0)
+    check("db", db, pq.grad.sum(0), tol(dtype, True) * 8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_residual(rts, dtype):
     from multimodal_sc_amd import functional as F
     rt = rts[dtype]
