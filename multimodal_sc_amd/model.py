@@ -329,6 +329,7 @@ class MultimodalSC:
                 torch.autograd.backward([out["patches"], out["head"]], [dpat, dhead])
             else:
                 torch.autograd.backward([out["patches"]], [dpat])
+            rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them
         return terms
 
     def metrics(self, terms):

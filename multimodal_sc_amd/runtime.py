@@ -10,6 +10,8 @@ Flat buffers make the DP all-reduce a handful of large RCCL calls and the optimi
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import lib as L
@@ -40,6 +42,9 @@ class Runtime:
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
         self.fused_attention = True  # bf16: flash-style kernel; False forces the batched-GEMM + softmax path (tests)
         self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
+        self.side = None                   # second HIP stream for the weight-gradient GEMMs (call_side / join_side)
+        self._side_dirty = False
+        self.wgrad_on_side = os.environ.get("MSC_SIDE_STREAM", "1") != "0"
         L.lib.load()                # fail loudly, now, if the HIP extension is missing
 
     @property
@@ -71,6 +76,28 @@ class Runtime:
         e1.record()
         self.profile.append((name, tuple(a for a in args if not hasattr(a, "data_ptr") and a is not None), e0, e1))
         return rc
+
+    def call_side(self, name, *args):
+        """Weight-gradient GEMMs are off the backward's critical path (nothing downstream reads them until the
+        optimizer), and many of them cannot fill 256 CUs on their own: enqueue them on a second HIP stream so the
+        hardware co-schedules them with the dgrad / normalisation chain on the main stream.  join_side() orders the main
+        stream behind them.  The instrumented (profile) pass stays on one stream for clean per-kernel timings."""
+        if not self.wgrad_on_side or self.profile is not None:
+            return self.call(name, *args)
+        if self.side is None:
+            self.side = torch.cuda.Stream(self.device)
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        rc = L.call(name, *args, self.side.cuda_stream)
+        for a in args:
+            if hasattr(a, "record_stream"):
+                a.record_stream(self.side)       # the caching allocator must not recycle these before the side stream is done
+        self._side_dirty = True
+        return rc
+
+    def join_side(self):
+        if self.side is not None and self._side_dirty:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._side_dirty = False
 
 
 class ParamStore:

@@ -65,6 +65,7 @@ class Trainer:
         works = []
         if self.world > 1 and self.overlap:
             def upper_ready():
+                m.rt.join_side()     # the upper weight gradients were produced on the side stream
                 works.append(dist.all_reduce(G[self.split:], op=dist.ReduceOp.SUM, async_op=True))
             m.rt.on_upper_grads_ready = upper_ready
         try:

@@ -26,6 +26,7 @@ def tol(dtype, fp32_out=False):
 
 
 def check(name, got, ref, t):
+    torch.cuda.synchronize()          # weight-gradient GEMMs run on the runtime's side stream
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
@@ -40,6 +41,7 @@ def check_grad(name, got, ref, t, dtype, relu):
     mask than in the fp32 reference, which moves a few isolated entries by O(|dy|) — a max-abs bound is the wrong
     yardstick for that.  Those cases use the relative Frobenius error (<= 4e-2); everything else uses max-abs."""
     if dtype == "bf16" and relu:
+        torch.cuda.synchronize()
         g, r = got.detach().double().cpu(), ref.detach().double().cpu()
         assert g.shape == r.shape and torch.isfinite(g).all(), name
         rel = ((g - r).norm() / r.norm().clamp_min(1e-30)).item()
