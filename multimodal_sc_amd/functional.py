@@ -53,7 +53,7 @@ def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, mean, rstd, conv: ParamRef, gamma:
     rt.call("msc_bn_bwd", dy, y_raw, y, mean, rstd, gamma.p, d_raw, dres, gamma.g, beta.g, ws, M, Cout, int(relu),
             rt.accumulate, rt.dt)
     wsb = L.query("msc_wgrad_workspace_bytes", Cout, KH * KW * Cin, M)
-    wsw = rt.workspace("wgrad", wsb)
+    wsw = rt.workspace("wgrad", wsb, per_stream=False)     # only the side stream touches it
     rt.call_side("msc_conv2d_wgrad", x, d_raw, conv.g, wsw, wsb, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.accumulate, rt.dt)
     dx = None
     if need_dx:
@@ -164,7 +164,7 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
         ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N))
         rt.call("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
-    wsw = rt.workspace("wgrad", wsb)
+    wsw = rt.workspace("wgrad", wsb, per_stream=False)     # only the side stream touches it
     rt.call_side("msc_linear_wgrad", x2d, d, w.g, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
     dx = None
     if need_dx:

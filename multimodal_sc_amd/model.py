@@ -265,8 +265,20 @@ class MultimodalSC:
         Returns dict: head [B,16] (logits 0..A-1, value at A), patches [B*G*G, P*P*3], symbols, rx, feature, z."""
         cfg, rt = self.cfg, self.rt
         B = image.shape[0]
-        img_tok = self.image_encoder(image)
-        bev_tok = self.bev_encoder(points) if cfg.use_lidar else None
+        if cfg.use_lidar and rt.branch_streams:
+            # camera and LiDAR branches are independent until the fusion: run the BEV branch on its own HIP stream so
+            # the two stacks of (often chip-underfilling) conv kernels overlap; autograd replays the backward of each
+            # node on the stream its forward ran on, so the backward overlaps the same way.
+            main, s2 = torch.cuda.current_stream(rt.device), rt.branch_stream()
+            s2.wait_stream(main)
+            with torch.cuda.stream(s2):
+                bev_tok = self.bev_encoder(points)
+            img_tok = self.image_encoder(image)
+            main.wait_stream(s2)
+            bev_tok.record_stream(main)
+        else:
+            img_tok = self.image_encoder(image)
+            bev_tok = self.bev_encoder(points) if cfg.use_lidar else None
         st_tok = self.state_encoder(state).view(B, 1, cfg.d_model) if cfg.use_state else None
         x = self.fusion(img_tok, bev_tok, st_tok)
         f = F.MeanPool.apply(x, rt)
@@ -330,6 +342,8 @@ class MultimodalSC:
             else:
                 torch.autograd.backward([out["patches"]], [dpat])
             rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them
+            if rt._branch is not None:
+                torch.cuda.current_stream(rt.device).wait_stream(rt._branch)
         return terms
 
     def metrics(self, terms):

@@ -44,6 +44,8 @@ class Runtime:
         self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
         self.side = None                   # second HIP stream for the weight-gradient GEMMs (call_side / join_side)
         self._side_dirty = False
+        self._branch = None
+        self.branch_streams = os.environ.get("MSC_BRANCH_STREAMS", "1") != "0"
         self.wgrad_on_side = os.environ.get("MSC_SIDE_STREAM", "1") != "0"
         L.lib.load()                # fail loudly, now, if the HIP extension is missing
 
@@ -57,14 +59,23 @@ class Runtime:
     def f32(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
-    def workspace(self, name: str, nbytes: int) -> torch.Tensor:
-        """Persistent fp32 scratch (grown on demand; sizes settle during the warm-up step before graph capture)."""
+    def workspace(self, name: str, nbytes: int, per_stream: bool = True) -> torch.Tensor:
+        """Persistent fp32 scratch, grown on demand.  One buffer per (name, HIP stream): the encoder branches run on
+        different streams and must not share reduction scratch.  per_stream=False: buffers only ever touched from the
+        weight-gradient side stream."""
         n = (int(nbytes) + 3) // 4
-        t = self._ws.get(name)
+        key = (name, torch.cuda.current_stream(self.device).cuda_stream if per_stream else 0)
+        t = self._ws.get(key)
         if t is None or t.numel() < n:
             t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
-            self._ws[name] = t
+            self._ws[key] = t
         return t
+
+    def branch_stream(self):
+        """second compute stream for the LiDAR/BEV branch (independent of the camera branch until the fusion)"""
+        if self._branch is None:
+            self._branch = torch.cuda.Stream(self.device)
+        return self._branch
 
     def call(self, name, *args):
         if self.profile is None:
