@@ -26,6 +26,7 @@
 // Build-authored: the upstream reference has no code (SURVEY.md finding zero); roles per BASELINE.json:
 // ImageEncoder/BEV conv stack, FusionTransformer, SemanticEncoder/Decoder, heads.
 #include "msc_common.h"
+#include <stdlib.h>
 
 enum { OPM_DENSE_K = 0, OPM_DENSE_MN = 1, OPM_CONV_FWD = 2, OPM_CONV_DGRAD = 3, OPM_CONV_WGRAD = 4 };
 
@@ -706,7 +707,15 @@ static inline bool fits32(long elems, int dtype) { return elems * esize(dtype) <
 // split-K plan shared by the workspace query and the launchers (independent of dtype)
 static int plan_split(long rows_out, long cols_out, long reduce_len) {
   const long tiles = (long)cdiv(rows_out, 128) * cdiv(cols_out, cols_out <= 64 ? 64 : 128);
-  long want = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~512 workgroups measured best
+  // (fewer: underfilled when the main stream idles; more: fp32 slab traffic = nsplit x output)
+  static long target = 0;
+  if (!target) {
+    const char* e = getenv("MSC_WGRAD_BLOCKS");   // tuning knob (A/B runs); default 512 (measured best of 128..1536)
+    target = e ? atol(e) : 512;
+    if (target < 1) target = 512;
+  }
+  long want = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
   long cap = reduce_len / 1024;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -732,7 +741,10 @@ static int finish_wgrad(GemmParams& p, float* dw, float* ws, int64_t ws_bytes, l
   p.C = ws;
   p.ldc = p.N;
   p.out_f32 = 1;
-  // nsplit == 1 still goes through the slab so that `accumulate` has one implementation
+  if (ns == 1 && !accumulate) {   // no slab, no reduce pass: the GEMM epilogue writes dw itself
+    p.C = dw;
+    return launch(p, 1, dtype, st);
+  }
   int rc = launch(p, 1, dtype, st);
   if (rc != MSC_OK) return rc;
   const long n4 = (long)p.M * p.N / 4;

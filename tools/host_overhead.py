@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""How long does the host take to ENQUEUE one training step (no sync) vs the GPU to run it?"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_sc_amd.model import MultimodalSC, named_config
+from multimodal_sc_amd.trainer import Trainer
+from oracle import model as O
+cfg = named_config("C3")
+m = MultimodalSC(cfg, "bf16", "cuda:0")
+tr = Trainer(m)
+cb = O.synthetic_batch(O.named_config("C3"), 64, seed=1)
+b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cb.items() if k != "ppo"}
+b["ppo"] = {k: v.cuda() for k, v in cb["ppo"].items()}
+b["noise"] = b["fading"] = None
+for _ in range(3):
+    tr.step(b)
+torch.cuda.synchronize()
+enq = []
+t0 = time.perf_counter()
+for _ in range(10):
+    t = time.perf_counter()
+    tr.step(b)
+    enq.append(time.perf_counter() - t)
+torch.cuda.synchronize()
+tot = (time.perf_counter() - t0) / 10
+print(f"host enqueue per step: {1e3*sum(enq)/10:.2f} ms   wall per step: {1e3*tot:.2f} ms")
