@@ -150,14 +150,19 @@ int msc_permute3_cast(const float* src, void* dst, int d0, int d1, int d2, int d
 int msc_permute3_cast_batched(const float* P, void* TR, const int64_t* table, int n_entries, int total_blocks,
                               int dtype, void* stream);
 /* torch.optim.Adam semantics; shadow (T, may be NULL) receives the updated low-precision copy */
+/* step_dev (optional, device int64): step counter read by the kernel instead of `step` (survives hipGraph replay) */
 int msc_adam_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int step, float grad_scale, int dtype, void* stream);
+                  float beta2, float eps, float weight_decay, int step, const int64_t* step_dev, float grad_scale,
+                  int dtype, void* stream);
+int msc_counter_add(int64_t* ctr, int64_t inc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SemanticEncoder power normalisation + Channel (AWGN / Rayleigh).  x,y: T [B][k]; noise/fading:
  * fp32 [B][k] or NULL (then Philox4x32-10 with `seed`); snr_db: fp32 [B]; scale: fp32 [B] (saved). */
+/* seed_dev (optional, device int64) is added to `seed` inside the kernel (per-step noise under hipGraph replay) */
 int msc_channel_fwd(const void* x, const float* noise, const float* fading, const float* snr_db, void* y,
-                    float* scale, int B, int k, int mode, uint64_t seed, int dtype, void* stream);
+                    float* scale, int B, int k, int mode, uint64_t seed, const int64_t* seed_dev, int dtype,
+                    void* stream);
 int msc_channel_bwd(const void* dy, const void* x, const float* scale, void* dx, int B, int k, int dtype,
                     void* stream);
 int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, void* stream);

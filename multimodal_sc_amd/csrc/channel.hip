@@ -48,7 +48,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void channel_fwd_kernel(const T* __restrict__ x, const float* __restrict__ noise,
                                                           const float* __restrict__ fading, const float* __restrict__ snr_db,
                                                           T* __restrict__ y, float* __restrict__ scale, int B, int k, int mode,
-                                                          uint64_t seed) {
+                                                          uint64_t seed, const int64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += (uint64_t)*seed_dev;   // device-side step counter: fresh noise on every hipGraph replay
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -141,14 +142,14 @@ __global__ void philox_fill_kernel(float* __restrict__ out, long nquads, uint64_
 }
 
 extern "C" int msc_channel_fwd(const void* x, const float* noise, const float* fading, const float* snr_db, void* y, float* scale,
-                               int B, int k, int mode, uint64_t seed, int dtype, void* stream) {
+                               int B, int k, int mode, uint64_t seed, const int64_t* seed_dev, int dtype, void* stream) {
   MSC_CHECK_ARG(x && snr_db && y && scale && B > 0 && k > 0 && k % 4 == 0 && k <= 64 * 4 * CH_MAXQ);
   MSC_CHECK_ARG(mode == MSC_CH_AWGN || mode == MSC_CH_RAYLEIGH);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSC_F32)
-    hipLaunchKernelGGL(channel_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)x, noise, fading, snr_db, (float*)y, scale, B, k, mode, seed);
+    hipLaunchKernelGGL(channel_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)x, noise, fading, snr_db, (float*)y, scale, B, k, mode, seed, seed_dev);
   else if (dtype == MSC_BF16)
-    hipLaunchKernelGGL(channel_fwd_kernel<bf16_t>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const bf16_t*)x, noise, fading, snr_db, (bf16_t*)y, scale, B, k, mode, seed);
+    hipLaunchKernelGGL(channel_fwd_kernel<bf16_t>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const bf16_t*)x, noise, fading, snr_db, (bf16_t*)y, scale, B, k, mode, seed, seed_dev);
   else
     return MSC_ERR_BAD_ARG;
   return msc_launch_status();
@@ -163,6 +164,15 @@ extern "C" int msc_channel_bwd(const void* dy, const void* x, const float* scale
     hipLaunchKernelGGL(channel_bwd_kernel<bf16_t>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, scale, (bf16_t*)dx, B, k);
   else
     return MSC_ERR_BAD_ARG;
+  return msc_launch_status();
+}
+
+__global__ void counter_add_kernel(int64_t* ctr, int64_t inc) { *ctr += inc; }
+
+// ctr[0] += inc on the stream (device-side step / seed counters that survive hipGraph replay)
+extern "C" int msc_counter_add(int64_t* ctr, int64_t inc, void* stream) {
+  MSC_CHECK_ARG(ctr);
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
   return msc_launch_status();
 }
 

@@ -347,10 +347,6 @@ class TokensAssemble(torch.autograd.Function):
         cols = (n0 + n1 + n2) * D
         ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", B, cols))
         rt.call("msc_colsum", dout, pos.g, ws, B, cols, rt.accumulate, rt.dt)
-        # every gradient from fusion.pos_embed to the end of the flat buffer (transformer, codec, heads) is final now;
-        # the trainer uses this point to start their all-reduce under the encoder backward that follows
-        if rt.on_upper_grads_ready is not None:
-            rt.on_upper_grads_ready()
         return d0, d1, d2, None, None
 
 
@@ -374,11 +370,11 @@ class MeanPool(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ channel
 class ChannelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rt, snr_db, noise, fading, mode, seed):
+    def forward(ctx, x, rt, snr_db, noise, fading, mode, seed, seed_dev=None):
         B, k = x.shape
         y = rt.empty(B, k)
         scale = rt.f32(B)
-        rt.call("msc_channel_fwd", x, noise, fading, snr_db, y, scale, B, k, mode, int(seed), rt.dt)
+        rt.call("msc_channel_fwd", x, noise, fading, snr_db, y, scale, B, k, mode, int(seed), seed_dev, rt.dt)
         ctx.save_for_backward(x, scale)
         ctx.rt = rt
         return y
@@ -389,7 +385,7 @@ class ChannelFn(torch.autograd.Function):
         rt = ctx.rt
         dx = torch.empty_like(x)
         rt.call("msc_channel_bwd", dy.contiguous(), x, scale, dx, x.shape[0], x.shape[1], rt.dt)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ LiDAR pillars

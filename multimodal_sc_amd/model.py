@@ -275,17 +275,26 @@ class MultimodalSC:
                 bev_tok = self.bev_encoder(points)
             img_tok = self.image_encoder(image)
             main.wait_stream(s2)
-            bev_tok.record_stream(main)
+            if not torch.cuda.is_current_stream_capturing():
+                bev_tok.record_stream(main)
         else:
             img_tok = self.image_encoder(image)
             bev_tok = self.bev_encoder(points) if cfg.use_lidar else None
         st_tok = self.state_encoder(state).view(B, 1, cfg.d_model) if cfg.use_state else None
+        # autograd boundary between the encoders and everything downstream: the backward runs in two phases
+        # (upper: heads/codec/transformer; lower: encoders) so the trainer can start the all-reduce of the upper
+        # gradients before the encoder backward (DP overlap), also across hipGraph replays
+        self._enc_out = [t for t in (img_tok, bev_tok, st_tok) if t is not None]
+        self._enc_in = [t.detach().requires_grad_() for t in self._enc_out]
+        it = iter(self._enc_in)
+        img_tok = next(it)
+        bev_tok = next(it) if bev_tok is not None else None
+        st_tok = next(it) if st_tok is not None else None
         x = self.fusion(img_tok, bev_tok, st_tok)
         f = F.MeanPool.apply(x, rt)
         sym = self._lin(self._lin(f, "semantic_encoder.fc1", L.ACT_RELU), "semantic_encoder.fc2")
         mode = L.CH_AWGN if cfg.channel == "awgn" else L.CH_RAYLEIGH
-        self.channel_seed += 1
-        rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, self.channel_seed)
+        rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, self.channel_seed, self.params.step_dev)
         z = self._lin(self._lin(rx, "semantic_decoder.fc1", L.ACT_RELU), "semantic_decoder.fc2")
         head = self._lin(self._lin(z, "head.fc", L.ACT_TANH), "head.out")
         g = cfg.recon_grid
@@ -317,7 +326,16 @@ class MultimodalSC:
         return img
 
     # ------------------------------------------------------------------ loss + backward
-    def loss_and_grads(self, out, image, ppo=None, backward=True):
+    def backward_lower(self):
+        """phase 2 of the backward: encoders (ResNet-18, BEV, state) from the gradients phase 1 left at the boundary"""
+        rt = self.rt
+        torch.autograd.backward(self._enc_out, [t.grad for t in self._enc_in])
+        self._enc_out = self._enc_in = None
+        rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them
+        if rt._branch is not None:
+            torch.cuda.current_stream(rt.device).wait_stream(rt._branch)
+
+    def loss_and_grads(self, out, image, ppo=None, backward=True, lower=True):
         """Fused loss kernels produce the loss terms AND d(loss)/d(head), d(loss)/d(patches); autograd then runs
         the kernel backward chain from those two gradients.  Returns dict of fp32 device scalars."""
         rt, cfg = self.rt, self.cfg
@@ -341,9 +359,12 @@ class MultimodalSC:
                 torch.autograd.backward([out["patches"], out["head"]], [dpat, dhead])
             else:
                 torch.autograd.backward([out["patches"]], [dpat])
-            rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them
-            if rt._branch is not None:
-                torch.cuda.current_stream(rt.device).wait_stream(rt._branch)
+            # upper gradients (flat buffer from fusion.pos_embed on) are final once the side stream is joined
+            if rt.on_upper_grads_ready is not None:
+                rt.join_side()
+                rt.on_upper_grads_ready()
+            if lower:
+                self.backward_lower()
         return terms
 
     def metrics(self, terms):

@@ -99,9 +99,10 @@ class Runtime:
             self.side = torch.cuda.Stream(self.device)
         self.side.wait_stream(torch.cuda.current_stream(self.device))
         rc = L.call(name, *args, self.side.cuda_stream)
-        for a in args:
-            if hasattr(a, "record_stream"):
-                a.record_stream(self.side)       # the caching allocator must not recycle these before the side stream is done
+        if not torch.cuda.is_current_stream_capturing():   # under hipGraph capture the pool is static: nothing to guard
+            for a in args:
+                if hasattr(a, "record_stream"):
+                    a.record_stream(self.side)   # the caching allocator must not recycle these before the side stream is done
         self._side_dirty = True
         return rc
 
@@ -138,6 +139,7 @@ class ParamStore:
             r.c = self.C[sl].view(r.shape)
             r.t = self.TR[sl] if r.kind in ("conv", "linear") else None
         self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # device-side step counter (hipGraph replay)
         self._ptable = None
 
     def __getitem__(self, name) -> ParamRef:
@@ -167,7 +169,8 @@ class ParamStore:
     def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         rt = self.rt
         self.step_count += 1
+        rt.call("msc_counter_add", self.step_dev, 1)          # the kernels read the step from device memory, so the
         rt.call("msc_adam_step", self.P, self.G, self.M, self.V, None if rt.dt == L.MSC_F32 else self.C, self.total,
-                float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.step_count,
-                float(grad_scale), rt.dt)
+                float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, self.step_dev,
+                float(grad_scale), rt.dt)                       # same launches replay correctly from a hipGraph
         self.refresh_compute_copies(cast=False)

@@ -175,3 +175,26 @@ def test_training_reduces_loss(cuda):
         losses.append(m.metrics(terms)["mse"])
         m.params.adam_step(lr=2e-3)
     assert losses[-1] < losses[0] * 0.9, losses
+
+
+def test_hipgraph_replay_matches_eager(cuda, monkeypatch):
+    """Trainer.step captured into hipGraphs (opt-in, MSC_HIP_GRAPH=1: two eager warm-up steps, then replays) must leave
+    bit-identical parameters to the eager launch path — same kernels, same order, step counter / noise seed read from device memory."""
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from multimodal_sc_amd.trainer import Trainer
+    from oracle import model as O
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MSC_HIP_GRAPH", mode)
+        m = MultimodalSC(named_config("C3"), dtype="bf16", device="cuda:0", seed=3)
+        tr = Trainer(m, lr=1e-3)
+        gb = _to(m.rt.device, O.synthetic_batch(O.named_config("C3"), 2, seed=5))
+        gb["noise"] = gb["fading"] = None          # in-kernel Philox noise keyed by the device-side step counter
+        for _ in range(6):
+            terms = tr.step(gb)
+        torch.cuda.synchronize()
+        assert (tr._graphs is not None) == (mode == "1"), "graph path not taken / taken unexpectedly"
+        res[mode] = (m.params.P.clone(), terms["sse"].clone())
+    assert torch.equal(res["0"][0], res["1"][0])
+    assert torch.equal(res["0"][1], res["1"][1])
+    assert torch.isfinite(res["1"][0]).all()
