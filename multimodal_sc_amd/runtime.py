@@ -44,6 +44,7 @@ class Runtime:
         self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
         self.side = None                   # second HIP stream for the weight-gradient GEMMs (call_side / join_side)
         self._side_dirty = False
+        self.capture_keep = []
         self._branch = None
         self.branch_streams = os.environ.get("MSC_BRANCH_STREAMS", "1") != "0"
         self.wgrad_on_side = os.environ.get("MSC_SIDE_STREAM", "1") != "0"
@@ -99,7 +100,11 @@ class Runtime:
             self.side = torch.cuda.Stream(self.device)
         self.side.wait_stream(torch.cuda.current_stream(self.device))
         rc = L.call(name, *args, self.side.cuda_stream)
-        if not torch.cuda.is_current_stream_capturing():   # under hipGraph capture the pool is static: nothing to guard
+        if torch.cuda.is_current_stream_capturing():
+            # the graph pool would hand a block freed during capture to a later main-stream kernel although the side
+            # branch still reads it: keep every operand alive until the capture ends (Trainer clears the list)
+            self.capture_keep.extend(a for a in args if hasattr(a, "data_ptr"))
+        else:
             for a in args:
                 if hasattr(a, "record_stream"):
                     a.record_stream(self.side)   # the caching allocator must not recycle these before the side stream is done

@@ -147,6 +147,7 @@ class Trainer:
                 self._adam()
         self._graphs = (gA, gB, gC)
         self._terms = terms
+        m.rt.capture_keep.clear()
         # capture only RECORDS the launches: the step this call stands for still has to run
         return self._replay(batch)
 

@@ -184,7 +184,8 @@ def test_hipgraph_replay_matches_eager(cuda, monkeypatch):
     from multimodal_sc_amd.trainer import Trainer
     from oracle import model as O
     res = {}
-    for mode in ("0", "1"):
+    for tag in ("0", "0b", "1"):
+        mode = tag[0]
         monkeypatch.setenv("MSC_HIP_GRAPH", mode)
         m = MultimodalSC(named_config("C3"), dtype="bf16", device="cuda:0", seed=3)
         tr = Trainer(m, lr=1e-3)
@@ -194,7 +195,8 @@ def test_hipgraph_replay_matches_eager(cuda, monkeypatch):
             terms = tr.step(gb)
         torch.cuda.synchronize()
         assert (tr._graphs is not None) == (mode == "1"), "graph path not taken / taken unexpectedly"
-        res[mode] = (m.params.P.clone(), terms["sse"].clone())
+        res[tag] = (m.params.P.clone(), terms["sse"].clone())
+    assert torch.equal(res["0"][0], res["0b"][0]), "eager multi-stream steps are not reproducible"
     assert torch.equal(res["0"][0], res["1"][0])
     assert torch.equal(res["0"][1], res["1"][1])
     assert torch.isfinite(res["1"][0]).all()
