@@ -654,7 +654,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
 static void choose_tile(long M, long N, long zs, int& bm, int& bn, bool allow256 = true) {
   bm = M <= 64 ? 64 : 128;
   bn = N <= 64 ? 64 : 128;
-  // 256x128 tiles (8 waves) raise the FLOPs per byte staged into LDS from 64 to 85; used when they still fill the chip
+  // Measured (tools/gemm_ceiling.py): the kernel runs at the same rate whether its operands stream from HBM or sit in
+  // cache — the bound is the per-CU LDS fill path (LDS-DMA, ~55 GB/s per CU), so FLOPs per staged byte is the lever:
+  // 256x128 tiles (8 waves) raise it from 64 to 85 and are used when they still fill the chip.  A 256x256 tile (128
+  // FLOP/B, one workgroup per CU) was built and measured: slower at this path's short K (16-72 steps), where the
+  // un-overlapped prologue/epilogue of a lone workgroup costs more than the fill it saves.
   if (allow256 && bn == 128 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 128) * zs >= 256) { bm = 256; return; }
   if (bn == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bn = 64;
   if (bm == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bm = 64;
