@@ -161,8 +161,8 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
     else:
         d = dy2d
     if b is not None and not bias_done:
-        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N))
-        rt.call("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)
+        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N), per_stream=False)
+        rt.call_side("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)      # bias gradient: off the critical path
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
     wsw = rt.workspace("wgrad", wsb, per_stream=False)     # only the side stream touches it
     rt.call_side("msc_linear_wgrad", x2d, d, w.g, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
@@ -345,8 +345,8 @@ class TokensAssemble(torch.autograd.Function):
         d2 = rt.empty(B, n2, D) if n2 else None
         rt.call("msc_tokens_split", dout, d0, d1, d2, B, n0, n1, n2, D, rt.dt)
         cols = (n0 + n1 + n2) * D
-        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", B, cols))
-        rt.call("msc_colsum", dout, pos.g, ws, B, cols, rt.accumulate, rt.dt)
+        ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", B, cols), per_stream=False)
+        rt.call_side("msc_colsum", dout, pos.g, ws, B, cols, rt.accumulate, rt.dt)
         return d0, d1, d2, None, None
 
 
@@ -407,7 +407,7 @@ class PillarFn(torch.autograd.Function):
         points, grid32 = ctx.saved_tensors
         rt, w, b, G, rng, cell = ctx.cfg
         B, Np, _ = points.shape
-        ws = rt.workspace("pillar", L.query("msc_pillar_bwd_workspace_bytes"))
-        rt.call("msc_pillar_bwd", points, w.p, b.p, grid32, dgrid.contiguous(), w.g, b.g, ws, B, Np, G, w.shape[0], -rng, cell,
+        ws = rt.workspace("pillar", L.query("msc_pillar_bwd_workspace_bytes"), per_stream=False)
+        rt.call_side("msc_pillar_bwd", points, w.p, b.p, grid32, dgrid.contiguous(), w.g, b.g, ws, B, Np, G, w.shape[0], -rng, cell,
                 rt.accumulate, rt.dt)
         return None, None, None, None, None, None, None
