@@ -146,14 +146,17 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
     bfx8 pb[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      float mx = -INFINITY;
+      // VALU diet: the ragged-tail mask only on the last key tile (wave-uniform branch); the row maximum is taken on the
+      // raw scores and scaled once (c_log2 > 0); scale and max-subtraction fold into one FMA per element below
+      if (kt == NT - 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool kv = kt * 32 + acc_row(r, lh) < T;
-        s[t][r] = kv ? s[t][r] * c_log2 : -INFINITY;
-        mx = fmaxf(mx, s[t][r]);
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + acc_row(r, lh) >= T) s[t][r] = -INFINITY;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float mx = s[t][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c_log2;
       if (__any(mx > m[t])) {            // exact online softmax; rescale only when some row's maximum moved
         const float mn = fmaxf(m[t], mx);
         const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m[t]);
+        s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], c_log2, -m[t]));
         ps += s[t][r];
       }
       l[t] += ps;
@@ -249,9 +252,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const bool kv = kt * 32 + acc_row(r, lh) < T;
-        const float p = kv ? __builtin_amdgcn_exp2f(s[r] * c_log2 - ls) : 0.f;
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c_log2, -ls));
         s[r] = p * (dp[r] - dl);                        // dS^T
+      }
+      if (kt == NT - 1) {                               // ragged tail: keys >= T carry no probability
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + acc_row(r, lh) >= T) s[r] = 0.f;
       }
       const bfx8 d0 = pack8(s, 0), d1 = pack8(s, 1);
 #pragma unroll
