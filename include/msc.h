@@ -34,6 +34,10 @@ enum { MSC_CH_AWGN = 0, MSC_CH_RAYLEIGH = 1 };
 
 const char* msc_strerror(int code);
 int msc_version(void);
+/* non-blocking HIP stream at a relative priority (-1 lowest, 0 default, +1 highest of the device's range); returns the
+   hipStream_t as an integer, 0 on failure.  Used for the training step's side stream (weight gradients). */
+int64_t msc_stream_create(int level);
+int msc_stream_destroy(int64_t stream);
 /* bytes of fp32 workspace msc_conv2d_wgrad / msc_linear_wgrad need for their split-K slabs */
 int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len);
 

@@ -51,6 +51,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #ifndef GEMM_STAGES
 #define GEMM_STAGES 3         // LDS buffers of the DMA pipeline (STAGES-1 K steps in flight)
 #endif
+// GEMM_ABLATE (tools/gemm_ablate.py only, never defined in the product build; results are WRONG by construction):
+//   1 no DMA inside the K loop   2 no MFMA (fragments still read)   3 no fragment reads, no MFMA   4 no epilogue stores
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KEEP_LIVE(x) asm volatile("" ::"v"(x))
+#else
+#define KEEP_LIVE(x) (void)(x)
+#endif
 
 template <int MODE> struct mode_is_kmajor { static constexpr bool value = (MODE == OPM_DENSE_K || MODE == OPM_CONV_FWD || MODE == OPM_CONV_DGRAD); };
 
@@ -381,14 +391,17 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
     if (nb >= STAGES) nb -= STAGES;
     char* nxt = smem + nb * STAGE_BYTES;
     if (more) {
-      if constexpr (LA::DMA) la.issue(p, p.K, nxt, ks); else la.load(p, p.K, ra, ks);
-      if constexpr (LB::DMA) lb.issue(p, p.K, nxt + A_BYTES, ks); else lb.load(p, p.K, rb, ks);
+      if constexpr (GEMM_ABLATE != 1) {
+        if constexpr (LA::DMA) la.issue(p, p.K, nxt, ks); else la.load(p, p.K, ra, ks);
+        if constexpr (LB::DMA) lb.issue(p, p.K, nxt + A_BYTES, ks); else lb.load(p, p.K, rb, ks);
+      }
       advance();
       ++issued;
     }
     const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + A_BYTES;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (GEMM_ABLATE == 3) {
+    } else if constexpr (sizeof(T) == 2) {
       // lane geometry of the transposed read (mn-major images): 16-lane group g, row q / column quad pq inside it
       const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
 #pragma unroll
@@ -430,7 +443,8 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if constexpr (GEMM_ABLATE == 2) { KEEP_LIVE(fa[i]); KEEP_LIVE(fb[j]); }
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -463,6 +477,13 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
   __syncthreads();
+  if constexpr (GEMM_ABLATE == 4) {   // keep the accumulators live, store nothing
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) KEEP_LIVE(acc[i][j]);
+    if (p.M > 0) return;
+  }
 
   // ---------------------------------------------------------------- epilogue
   // (1) BatchNorm partial statistics straight from the fp32 accumulators (conv forward only)
@@ -637,13 +658,38 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
 }
 
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i]   (fixed order: bitwise reproducible)
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n4, int nsplit, int accumulate) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 s = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < nsplit; ++k) {
-      const float4 t = reinterpret_cast<const float4*>(slab)[(long)k * n4 + i];
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+// Block = 64 float4 columns x RY slab groups: small outputs with many slabs (early conv layers: 36 K elements x ~100
+// slabs) would otherwise walk the slabs serially from a handful of threads.  Group y sums slabs y, y+RY, ...; the groups
+// are combined through LDS in the order 0..RY-1.
+template <int RY>
+__global__ __launch_bounds__(64 * RY) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n4, int nsplit, int accumulate) {
+  __shared__ float4 part[RY][64];
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  const int y = threadIdx.y;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    int k = y;
+    for (; k + RY < nsplit; k += 2 * RY) {   // two independent loads in flight
+      const float4 t0 = reinterpret_cast<const float4*>(slab)[(long)k * n4 + i];
+      const float4 t1 = reinterpret_cast<const float4*>(slab)[(long)(k + RY) * n4 + i];
+      s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+      s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
     }
+    if (k < nsplit) {
+      const float4 t0 = reinterpret_cast<const float4*>(slab)[(long)k * n4 + i];
+      s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+    }
+  }
+  if (RY > 1) {
+    part[y][threadIdx.x] = s;
+    __syncthreads();
+    if (y != 0) return;
+    s = part[0][threadIdx.x];
+#pragma unroll
+    for (int r = 1; r < RY; ++r) { const float4 t = part[r][threadIdx.x]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+  }
+  if (i < n4) {
+    if (accumulate) { const float4 o = reinterpret_cast<const float4*>(out)[i]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
     reinterpret_cast<float4*>(out)[i] = s;
   }
 }
@@ -752,9 +798,15 @@ static int finish_wgrad(GemmParams& p, float* dw, float* ws, int64_t ws_bytes, l
   int rc = launch(p, 1, dtype, st);
   if (rc != MSC_OK) return rc;
   const long n4 = (long)p.M * p.N / 4;
-  int blocks = cdiv(n4, 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, n4, ns, accumulate);
+  const unsigned blocks = (unsigned)cdiv(n4, 64);
+  // slab groups per block: as many as keep >= ~4 waves per CU busy, at most the slab count
+  int ry = 1;
+  while (ry < 16 && ry * 2 <= ns && (long)blocks * ry < 4096) ry *= 2;
+  if (ry == 1) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(64, 1), 0, st, ws, dw, n4, ns, accumulate);
+  else if (ry == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(blocks), dim3(64, 2), 0, st, ws, dw, n4, ns, accumulate);
+  else if (ry == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(64, 4), 0, st, ws, dw, n4, ns, accumulate);
+  else if (ry == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(blocks), dim3(64, 8), 0, st, ws, dw, n4, ns, accumulate);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(blocks), dim3(64, 16), 0, st, ws, dw, n4, ns, accumulate);
   return msc_launch_status();
 }
 

@@ -166,3 +166,18 @@ extern "C" const char* msc_strerror(int code) {
   }
 }
 extern "C" int msc_version(void) { return 100; }
+
+// A non-blocking HIP stream at a priority level relative to the device's range: -1 lowest, 0 default, +1 highest.
+// Returns the hipStream_t as an integer (0 on failure).  The side stream of the training step (weight gradients, bias
+// column sums) is created at the lowest level so the dgrad / normalisation chain wins the CUs when both have work.
+extern "C" int64_t msc_stream_create(int level) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 0;
+  const int prio = level < 0 ? least : (level > 0 ? greatest : 0);
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) return 0;
+  return (int64_t)(intptr_t)st;
+}
+extern "C" int msc_stream_destroy(int64_t stream) {
+  return hipStreamDestroy((hipStream_t)(intptr_t)stream) == hipSuccess ? MSC_OK : MSC_ERR_BAD_ARG;
+}

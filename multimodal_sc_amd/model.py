@@ -285,6 +285,7 @@ class MultimodalSC:
         # (upper: heads/codec/transformer; lower: encoders) so the trainer can start the all-reduce of the upper
         # gradients before the encoder backward (DP overlap), also across hipGraph replays
         self._enc_out = [t for t in (img_tok, bev_tok, st_tok) if t is not None]
+        self._bev_slot = 1 if bev_tok is not None else None
         self._enc_in = [t.detach().requires_grad_() for t in self._enc_out]
         it = iter(self._enc_in)
         img_tok = next(it)
@@ -329,7 +330,14 @@ class MultimodalSC:
     def backward_lower(self):
         """phase 2 of the backward: encoders (ResNet-18, BEV, state) from the gradients phase 1 left at the boundary"""
         rt = self.rt
-        torch.autograd.backward(self._enc_out, [t.grad for t in self._enc_in])
+        outs, grads = self._enc_out, [t.grad for t in self._enc_in]
+        if self._bev_slot is not None and rt._branch is not None:
+            # autograd would replay the branch whose forward was recorded first (BEV) LAST, i.e. enqueue it behind the whole
+            # ResNet backward and leave it as a ~1 ms tail on an otherwise idle chip: enqueue it first, on its own stream
+            i = self._bev_slot
+            torch.autograd.backward([outs[i]], [grads[i]])
+            outs, grads = outs[:i] + outs[i + 1:], grads[:i] + grads[i + 1:]
+        torch.autograd.backward(outs, grads)
         self._enc_out = self._enc_in = None
         rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them
         if rt._branch is not None:

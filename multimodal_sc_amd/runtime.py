@@ -97,7 +97,7 @@ class Runtime:
         if not self.wgrad_on_side or self.profile is not None:
             return self.call(name, *args)
         if self.side is None:
-            self.side = torch.cuda.Stream(self.device)
+            self.side = self._make_side_stream()
         self.side.wait_stream(torch.cuda.current_stream(self.device))
         rc = L.call(name, *args, self.side.cuda_stream)
         if torch.cuda.is_current_stream_capturing():
@@ -110,6 +110,18 @@ class Runtime:
                     a.record_stream(self.side)   # the caching allocator must not recycle these before the side stream is done
         self._side_dirty = True
         return rc
+
+    def _make_side_stream(self):
+        """The side stream runs at the LOWEST HIP priority: its kernels fill CUs the critical chain leaves idle instead
+        of competing with it (MSC_SIDE_PRIO=0 keeps the default priority)."""
+        level = int(os.environ.get("MSC_SIDE_PRIO", "-1"))
+        if level == 0:
+            return torch.cuda.Stream(self.device)
+        with torch.cuda.device(self.device):
+            h = L.query("msc_stream_create", level)
+        if not h:
+            raise RuntimeError("msc_stream_create failed")
+        return torch.cuda.ExternalStream(h, device=self.device)
 
     def join_side(self):
         if self.side is not None and self._side_dirty:
