@@ -38,6 +38,10 @@ int msc_version(void);
    hipStream_t as an integer, 0 on failure.  Used for the training step's side stream (weight gradients). */
 int64_t msc_stream_create(int level);
 int msc_stream_destroy(int64_t stream);
+/* reusable hipEvent_t (timing disabled) as an integer, 0 on failure; msc_stream_wait_stream: `waiter` waits for all work
+   enqueued so far on `signaler` (hipEventRecord + hipStreamWaitEvent on that event) */
+int64_t msc_event_create(void);
+int msc_stream_wait_stream(void* waiter, void* signaler, int64_t event);
 /* bytes of fp32 workspace msc_conv2d_wgrad / msc_linear_wgrad need for their split-K slabs */
 int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len);
 

@@ -178,6 +178,19 @@ extern "C" int64_t msc_stream_create(int level) {
   if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) return 0;
   return (int64_t)(intptr_t)st;
 }
+// One reusable event + "waiter waits for everything enqueued so far on signaler" (event record + stream wait).
+extern "C" int64_t msc_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return 0;
+  return (int64_t)(intptr_t)ev;
+}
+extern "C" int msc_stream_wait_stream(void* waiter, void* signaler, int64_t event) {
+  hipEvent_t ev = (hipEvent_t)(intptr_t)event;
+  if (!ev) return MSC_ERR_BAD_ARG;
+  if (hipEventRecord(ev, (hipStream_t)signaler) != hipSuccess) return MSC_ERR_LAUNCH;
+  if (hipStreamWaitEvent((hipStream_t)waiter, ev, 0) != hipSuccess) return MSC_ERR_LAUNCH;
+  return MSC_OK;
+}
 extern "C" int msc_stream_destroy(int64_t stream) {
   return hipStreamDestroy((hipStream_t)(intptr_t)stream) == hipSuccess ? MSC_OK : MSC_ERR_BAD_ARG;
 }

@@ -334,8 +334,15 @@ class MultimodalSC:
         if self._bev_slot is not None and rt._branch is not None:
             # autograd would replay the branch whose forward was recorded first (BEV) LAST, i.e. enqueue it behind the whole
             # ResNet backward and leave it as a ~1 ms tail on an otherwise idle chip: enqueue it first, on its own stream
+            # (with the branch stream current: the engine ends a backward by making the CALLER's stream wait for every
+            # stream it used, which would stall the main stream for the whole BEV backward)
             i = self._bev_slot
-            torch.autograd.backward([outs[i]], [grads[i]])
+            main, s2 = torch.cuda.current_stream(rt.device), rt._branch
+            s2.wait_stream(main)
+            if not torch.cuda.is_current_stream_capturing():
+                grads[i].record_stream(s2)
+            with torch.cuda.stream(s2):
+                torch.autograd.backward([outs[i]], [grads[i]])
             outs, grads = outs[:i] + outs[i + 1:], grads[:i] + grads[i + 1:]
         torch.autograd.backward(outs, grads)
         self._enc_out = self._enc_in = None

@@ -30,6 +30,9 @@ class ParamRef:
         self.p = self.c = self.t = self.g = None
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
 class Runtime:
     def __init__(self, dtype: str = "bf16", device: str = "cuda:0"):
         assert dtype in ("bf16", "f32")
@@ -37,6 +40,7 @@ class Runtime:
         self.tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.vec = 8 if dtype == "bf16" else 4
         self.device = torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else 0
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
@@ -44,6 +48,7 @@ class Runtime:
         self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
         self.side = None                   # second HIP stream for the weight-gradient GEMMs (call_side / join_side)
         self._side_dirty = False
+        self._side_keep = []
         self.capture_keep = []
         self._branch = None
         self.branch_streams = os.environ.get("MSC_BRANCH_STREAMS", "1") != "0"
@@ -52,7 +57,8 @@ class Runtime:
 
     @property
     def stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """raw hipStream_t of torch's current stream (the C-level query: this runs once per kernel launch)"""
+        return _raw_stream(self._dev_index)
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
@@ -65,7 +71,7 @@ class Runtime:
         different streams and must not share reduction scratch.  per_stream=False: buffers only ever touched from the
         weight-gradient side stream."""
         n = (int(nbytes) + 3) // 4
-        key = (name, torch.cuda.current_stream(self.device).cuda_stream if per_stream else 0)
+        key = (name, _raw_stream(self._dev_index) if per_stream else 0)
         t = self._ws.get(key)
         if t is None or t.numel() < n:
             t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
@@ -98,16 +104,17 @@ class Runtime:
             return self.call(name, *args)
         if self.side is None:
             self.side = self._make_side_stream()
-        self.side.wait_stream(torch.cuda.current_stream(self.device))
-        rc = L.call(name, *args, self.side.cuda_stream)
-        if torch.cuda.is_current_stream_capturing():
-            # the graph pool would hand a block freed during capture to a later main-stream kernel although the side
-            # branch still reads it: keep every operand alive until the capture ends (Trainer clears the list)
-            self.capture_keep.extend(a for a in args if hasattr(a, "data_ptr"))
-        else:
-            for a in args:
-                if hasattr(a, "record_stream"):
-                    a.record_stream(self.side)   # the caching allocator must not recycle these before the side stream is done
+            self._side_raw = self.side.cuda_stream
+            self._side_event = L.query("msc_event_create")
+            if not self._side_event:
+                raise RuntimeError("msc_event_create failed")
+        # side stream waits for everything enqueued so far on the launching stream (one reusable event, one C call)
+        L.call("msc_stream_wait_stream", self._side_raw, _raw_stream(self._dev_index), self._side_event)
+        rc = L.call(name, *args, self._side_raw)
+        # The operands are read on the side stream but owned (for the caching allocator) by the launching stream: keep
+        # them alive until join_side() has ordered the launching streams behind the side stream.  Cheaper than
+        # record_stream per operand, and also what a hipGraph capture needs (Trainer clears capture_keep after capture).
+        (self.capture_keep if torch.cuda.is_current_stream_capturing() else self._side_keep).append(args)
         self._side_dirty = True
         return rc
 
@@ -127,6 +134,7 @@ class Runtime:
         if self.side is not None and self._side_dirty:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self._side_dirty = False
+            self._side_keep.clear()
 
 
 class ParamStore:

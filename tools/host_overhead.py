@@ -25,3 +25,13 @@ for _ in range(10):
 torch.cuda.synchronize()
 tot = (time.perf_counter() - t0) / 10
 print(f"host enqueue per step: {1e3*sum(enq)/10:.2f} ms   wall per step: {1e3*tot:.2f} ms")
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        tr.step(b)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)
