@@ -150,6 +150,16 @@ int msc_meanpool_bwd(const void* dy, void* dx, int B, int T, int D, int dtype, v
 /* ref = output for relu/tanh/sigmoid, pre-activation for gelu */
 int msc_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, int dtype, void* stream);
 int msc_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
+
+/* ---- OCP e4m3 fp8 path of the semantic encoder / decoder GEMMs (configs[4]) ----
+ * Per-tensor quantisation by ONE workgroup (codec-sized tensors, n % 4 == 0, n <= 2^24): scale_out[0] = amax/448 (1 when
+ * amax == 0); q[i] = rne_e4m3(x[i] * (448/amax)) as bytes; deq (optional) = q * scale in deq_dtype — the straight-through
+ * operand the backward GEMMs use. */
+int msc_fp8_quantize(const void* x, void* q, void* deq, float* scale_out, int64_t n, int in_dtype, int deq_dtype,
+                     void* stream);
+/* y[M][N] = act(sx[0]*sw[0] * (xq[M][K] . wq[N][K]^T) + bias) on v_mfma_f32_32x32x16_fp8_fp8; K % 32 == 0 */
+int msc_linear_fp8_fwd(const void* xq, const void* wq, const float* sx, const float* sw, const float* bias, void* y,
+                       int M, int N, int K, int act, int dtype, void* stream);
 /* dst[k][j][i] = src[i][j][k]; OHWI -> [Cin][KH*KW][Cout] with (d0,d1,d2)=(Cout,KH*KW,Cin); linear W^T with d1=1 */
 int msc_permute3_cast(const float* src, void* dst, int d0, int d1, int d2, int dtype, void* stream);
 /* every weight transpose of a step in one launch.  table (device, int64 [n][6]) = {src_off, dst_off, d0, d1, d2,

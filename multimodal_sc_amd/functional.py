@@ -196,6 +196,56 @@ class Linear(torch.autograd.Function):
         return (dx.view(shp) if dx is not None else None), None, None, None, None, None, None
 
 
+class LinearFP8(torch.autograd.Function):
+    """Semantic encoder / decoder GEMM on OCP e4m3 operands (BASELINE.json configs[4]); oracle: oracle.model.FP8Linear.
+    Forward: per-tensor quantise x (activations) and W (fp32 master), contraction on the fp8 MFMA, fused bias + activation.
+    Backward: straight-through on the de-quantised operands x^, W^ through the ordinary kernels
+    (dx = d W^ via the mn-major-B contraction — no transposed copy of W^ is made; dW = d^T x^)."""
+
+    @staticmethod
+    def forward(ctx, x, rt, w, b, act, need_dx):
+        x2d = x.reshape(-1, x.shape[-1])
+        M, K = x2d.shape
+        N = w.shape[0]
+        dev = rt.device
+        xq = torch.empty(M, K, dtype=torch.uint8, device=dev)
+        wq = torch.empty(N, K, dtype=torch.uint8, device=dev)
+        xh, wh = rt.empty(M, K), rt.empty(N, K)
+        sc = rt.f32(2)
+        rt.call("msc_fp8_quantize", x2d, xq, xh, sc[0:1], M * K, rt.dt, rt.dt)
+        rt.call("msc_fp8_quantize", w.p, wq, wh, sc[1:2], N * K, L.MSC_F32, rt.dt)
+        y = rt.empty(M, N)
+        rt.call("msc_linear_fp8_fwd", xq, wq, sc[0:1], sc[1:2], b.p if b is not None else None, y, M, N, K, act, rt.dt)
+        ctx.save_for_backward(xh, wh, y if act != L.ACT_NONE else None)
+        ctx.cfg = (rt, w, b, act, need_dx, x.shape)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, wh, ref = ctx.saved_tensors
+        rt, w, b, act, need_dx, shp = ctx.cfg
+        dy2d = dy.reshape(-1, dy.shape[-1]).contiguous()
+        M, N = dy2d.shape
+        K = xh.shape[1]
+        if act != L.ACT_NONE:
+            d = torch.empty_like(dy2d)
+            rt.call("msc_act_bwd", dy2d, ref, d, M * N, act, rt.dt)
+        else:
+            d = dy2d
+        if b is not None:
+            ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N), per_stream=False)
+            rt.call_side("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)
+        wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
+        wsw = rt.workspace("wgrad", wsb, per_stream=False)
+        rt.call_side("msc_linear_wgrad", xh, d, w.g, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
+        dx = None
+        if need_dx:
+            dx = rt.empty(M, K)
+            # dx[M][K] = d[M][N] . W^[N][K]: A k-major (reduction over N), B stored [reduction][column] = mn-major
+            rt.call("msc_gemm_batched", d, wh, dx, M, K, N, N, K, K, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0, rt.dt)
+        return (dx.view(shp) if dx is not None else None), None, None, None, None, None
+
+
 def layernorm_fwd(rt, x2d, g: ParamRef, b: ParamRef):
     R, D = x2d.shape
     y = torch.empty_like(x2d)

@@ -38,6 +38,7 @@ class MSCConfig:
     patch: int = 32
     recon_hidden: int = 64
     channel: str = "awgn"
+    codec_fp8: bool = False    # semantic encoder/decoder GEMMs on OCP e4m3 operands (configs[4])
     clip_eps: float = 0.2
     c_value: float = 0.5
     c_entropy: float = 0.01
@@ -67,7 +68,7 @@ def named_config(name: str) -> MSCConfig:
         "C1": dict(img_size=224, use_lidar=False, use_state=False),
         "C2": dict(img_size=224, use_lidar=True, use_state=False),
         "C3": dict(img_size=224, use_lidar=True, use_state=True),
-        "C4": dict(img_size=224, use_lidar=True, use_state=True, channel="rayleigh"),
+        "C4": dict(img_size=224, use_lidar=True, use_state=True, channel="rayleigh", codec_fp8=True),
     }
     return MSCConfig(**table[name])
 
@@ -257,6 +258,8 @@ class MultimodalSC:
 
     def _lin(self, x, name, act=L.ACT_NONE):
         P = self.params
+        if self.cfg.codec_fp8 and name.startswith("semantic_"):
+            return F.LinearFP8.apply(x, self.rt, P[f"{name}.weight"], P[f"{name}.bias"], act, True)
         return F.Linear.apply(x, None, self.rt, P[f"{name}.weight"], P[f"{name}.bias"], act, True)
 
     # ------------------------------------------------------------------ forward

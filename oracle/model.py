@@ -49,6 +49,7 @@ class MSCConfig:
     patch: int = 32
     recon_hidden: int = 64
     channel: str = "awgn"            # "awgn" | "rayleigh"
+    codec_fp8: bool = False          # semantic encoder/decoder GEMMs on OCP e4m3 operands (configs[4])
     clip_eps: float = 0.2
     c_value: float = 0.5
     c_entropy: float = 0.01
@@ -83,7 +84,7 @@ def named_config(name: str) -> MSCConfig:
     if name == "C3":
         return MSCConfig(img_size=224, use_lidar=True, use_state=True)
     if name == "C4":
-        return MSCConfig(img_size=224, use_lidar=True, use_state=True, channel="rayleigh")
+        return MSCConfig(img_size=224, use_lidar=True, use_state=True, channel="rayleigh", codec_fp8=True)
     raise ValueError(name)
 
 
@@ -257,11 +258,45 @@ class FusionTransformer(nn.Module):
         return _r(self.ln_f(x))
 
 
+def e4m3_rne(v: torch.Tensor) -> torch.Tensor:
+    """Round fp32 values to the OCP e4m3 grid (4 exponent bits, bias 7, 3 mantissa bits, max 448, subnormal step 2^-9),
+    nearest-even, saturating.  Written out with exact power-of-two arithmetic (no dependence on a library cast)."""
+    a = v.abs().clamp(max=448.0)
+    _, ex = torch.frexp(a)                         # a = m * 2^ex, m in [0.5, 1)
+    e = (ex - 1).clamp(min=-6)                     # subnormals share the exponent of the smallest normal
+    step = torch.ldexp(torch.ones_like(a), e - 3)
+    return torch.sign(v) * torch.round(a / step) * step      # torch.round: half to even
+
+
+def fp8_qdq(t: torch.Tensor) -> torch.Tensor:
+    """per-tensor e4m3 quantise / de-quantise: scale = amax/448, q = rne(t * (448/amax)), result q * scale"""
+    amax = t.detach().abs().max().to(torch.float32)
+    if float(amax) == 0.0:
+        return t * 0.0
+    scale = amax / 448.0
+    inv = 448.0 / amax
+    return e4m3_rne(t.to(torch.float32) * inv) * scale
+
+
+class FP8Linear(nn.Linear):
+    """y = x^ W^^T + b with x^, W^ the e4m3 quantise/de-quantise of x and W; backward straight-through on x^ and W^
+    (dx = dy W^, dW = dy^T x^), which is what multimodal_sc_amd.functional.LinearFP8 computes."""
+
+    def forward(self, x):
+        xh = x + (fp8_qdq(x) - x).detach()
+        wh = self.weight + (fp8_qdq(self.weight) - self.weight).detach()
+        return F.linear(xh, wh, self.bias)
+
+
+def _codec_linear(cfg, i, o):
+    return FP8Linear(i, o) if cfg.codec_fp8 else nn.Linear(i, o)
+
+
 class SemanticEncoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
-        self.fc1 = nn.Linear(cfg.d_model, cfg.d_model)
-        self.fc2 = nn.Linear(cfg.d_model, cfg.n_symbols)
+        self.fc1 = _codec_linear(cfg, cfg.d_model, cfg.d_model)
+        self.fc2 = _codec_linear(cfg, cfg.d_model, cfg.n_symbols)
 
     def forward(self, f):
         return _r(self.fc2(_r(F.relu(self.fc1(f)))))     # un-normalised symbols; Channel applies the power constraint
@@ -299,8 +334,8 @@ class Channel(nn.Module):
 class SemanticDecoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
-        self.fc1 = nn.Linear(cfg.n_symbols, cfg.d_model)
-        self.fc2 = nn.Linear(cfg.d_model, cfg.d_model)
+        self.fc1 = _codec_linear(cfg, cfg.n_symbols, cfg.d_model)
+        self.fc2 = _codec_linear(cfg, cfg.d_model, cfg.d_model)
 
     def forward(self, y):
         return _r(self.fc2(_r(F.relu(self.fc1(y)))))

@@ -538,3 +538,63 @@ def test_adam_matches_torch(rts):
         rt.call("msc_adam_step", p, (g * 4).to(rt.device), m, v, sh, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, step, None, 0.25, rt.dt)
     check("p", p, ref, 1e-6)
     assert torch.equal(sh.cpu(), p.cpu().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (e4m3) codec GEMMs
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fp8_quantize_matches_oracle_grid(rts, dtype):
+    """msc_fp8_quantize against the oracle's written-out e4m3 rounding: the scale and EVERY de-quantised value bit-exact
+    (fp32 input; bf16 mode: de-quantised values are exactly representable fp8 x scale products rounded once to bf16)."""
+    from oracle import model as O
+    rt = rts[dtype]
+    for n, sc in [(64 * 512, 1.0), (512 * 512, 0.03), (1028, 300.0)]:
+        x = rnd(n, seed=n, scale=sc)
+        x[5], x[6] = 0.0, -x.abs().max() * 1.0          # exact zero and the (negative) maximum
+        xin = q(x, dtype)
+        xd = dev(x, rt)
+        qb = torch.empty(n, dtype=torch.uint8, device=rt.device)
+        dq = rt.empty(n)
+        s = torch.empty(1, device=rt.device)
+        rt.call("msc_fp8_quantize", xd, qb, dq, s, n, rt.dt, rt.dt)
+        torch.cuda.synchronize()
+        amax = xin.abs().max()
+        assert s.item() == (amax / 448.0).item()
+        ref = O.fp8_qdq(xin)
+        ref = ref if dtype == "f32" else ref.to(torch.bfloat16).float()
+        assert torch.equal(dq.float().cpu(), ref), (dq.float().cpu() - ref).abs().max()
+        # the bytes decode (OCP e4m3fn) to the same grid values
+        dec = qb.cpu().view(torch.float8_e4m3fn).float() * s.item()
+        assert torch.equal(dec if dtype == "f32" else dec.to(torch.bfloat16).float(), ref)
+    z = torch.zeros(64, device=rt.device, dtype=rt.tdtype)
+    qb, dq, s = torch.empty(64, dtype=torch.uint8, device=rt.device), rt.empty(64), torch.empty(1, device=rt.device)
+    rt.call("msc_fp8_quantize", z, qb, dq, s, 64, rt.dt, rt.dt)
+    torch.cuda.synchronize()
+    assert s.item() == 1.0 and not qb.any() and not dq.any()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,act", [(64, 512, 512, 1), (64, 256, 512, 0), (37, 96, 256, 1), (512, 512, 256, 0)])
+def test_linear_fp8_fwd_bwd(rts, dtype, M, N, K, act):
+    """LinearFP8 (quantise + fp8 MFMA + straight-through backward) against oracle.FP8Linear on identical weights"""
+    from multimodal_sc_amd import functional as F
+    from oracle import model as O
+    rt = rts[dtype]
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
+    dy = rnd(M, N, seed=4)
+    lin = O.FP8Linear(K, N)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+        lin.bias.copy_(b)
+    xq = q(x, dtype).requires_grad_()
+    pre = lin(xq)
+    ref = torch.relu(pre) if act == 1 else pre
+    W, Bp = FakeParam(rt, w, "linear"), FakeParam(rt, b, "vec")
+    xd = dev(x, rt).requires_grad_()
+    y = F.LinearFP8.apply(xd, rt, W, Bp, act, True)
+    # the MFMA sums exact products of e4m3 values and scales once; the oracle multiplies de-quantised fp32 operands
+    check("y", y, ref, tol(dtype))
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    check_grad("dx", xd.grad, xq.grad, tol(dtype) * 2, dtype, act == 1)
+    check_grad("dw", W.g, lin.weight.grad, tol(dtype, True) * 4, dtype, act == 1)
+    check_grad("db", Bp.g, lin.bias.grad, tol(dtype, True) * 4, dtype, act == 1)

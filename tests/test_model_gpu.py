@@ -62,30 +62,45 @@ def _run_pair(name, B, dtype, ppo=True, with_f64=False):
     return om, oout, oterms, m, out, terms, batch, g64
 
 
-@pytest.mark.parametrize("name,B", [("C0", 8), ("C3", 2)])
+@pytest.mark.parametrize("name,B", [("C0", 8), ("C3", 2), ("C4", 2)])
 def test_f32_end_to_end_parity(cuda, name, B):
+    """C4 = Rayleigh channel + e4m3 semantic encoder/decoder GEMMs: an activation that sits within fp32 rounding of an
+    e4m3 rounding boundary may quantise one grid step (6 %) apart in the two implementations, so C4 compares the
+    codec-dependent tensors at 2e-2 instead of 1e-3 (one flipped element moves a 512-term dot product by ~4e-3) (PSNR and the bit-exact action check are unchanged)."""
     from oracle import model as O
     om, oout, oterms, m, out, terms, batch, g64 = _run_pair(name, B, "f32", with_f64=True)
     logits, value = m.logits_value(out)
-    assert (logits.cpu() - oout["logits"]).abs().max() < 1e-3
-    assert (value.cpu() - oout["value"]).abs().max() < 1e-3
-    assert (out["symbols"].float().cpu() - oout["symbols"]).abs().max() < 1e-3
-    assert (out["rx"].float().cpu() - oout["rx"]).abs().max() < 1e-3
-    assert (m.recon_image(out).cpu() - oout["recon"]).abs().max() < 1e-3
+    t = 2e-2 if name == "C4" else 1e-3
+    gslack = 2e-2 if name == "C4" else 5e-4
+    assert (logits.cpu() - oout["logits"]).abs().max() < t
+    assert (value.cpu() - oout["value"]).abs().max() < t
+    assert (out["symbols"].float().cpu() - oout["symbols"]).abs().max() < t
+    assert (out["rx"].float().cpu() - oout["rx"]).abs().max() < t * (10 if name == "C4" else 1)   # Rayleigh: equalised by 1/|h|^2
+    assert (m.recon_image(out).cpu() - oout["recon"]).abs().max() < t
     met = m.metrics(terms)
     opsnr = O.psnr(oout["recon"], batch["image"]).mean().item()
     assert abs(met["psnr"] - opsnr) < 1e-3, (met["psnr"], opsnr)                      # decoder-PSNR parity
     assert torch.equal(m.select_action(out).cpu(), O.select_action(oout["logits"]))   # actions bit-exact
     for k in ("mse", "policy", "value", "entropy", "loss"):
-        assert abs(met[k] - oterms[k]) < 1e-4 * max(1.0, abs(oterms[k])), (k, met[k], oterms[k])
+        assert abs(met[k] - oterms[k]) < (t / 10) * max(1.0, abs(oterms[k])), (k, met[k], oterms[k])
     gg = m.export_state_dict(grads=True)
     bad = []
     for k, p in om.named_parameters():
         ref64 = g64[k]
+        if name == "C4":
+            # e4m3 rounding decisions differ between ANY two runs whose activations differ in the last fp32 bits (the fp32
+            # oracle itself sits ~1 % from its fp64 run here), so element-wise bounds are meaningless; the codec kernels are
+            # held to tight bounds in test_kernels_gpu.py, and the whole-model gradient is checked for direction and norm
+            a, b = gg[k].double().flatten(), ref64.flatten()
+            cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+            nr = (a.norm() / b.norm().clamp_min(1e-300)).item()
+            if b.norm() > 0 and (cos < 0.97 or abs(nr - 1) > 0.1):
+                bad.append((k, cos, nr))
+            continue
         den = ref64.abs().max().item()
         e_gpu = (gg[k].double() - ref64).abs().max().item()
         e_f32 = (p.grad.double() - ref64).abs().max().item()
-        if e_gpu > 5 * e_f32 + 5e-4 * den + 1e-12:
+        if e_gpu > 5 * e_f32 + gslack * den + 1e-12:
             bad.append((k, e_gpu / max(den, 1e-30), e_f32 / max(den, 1e-30)))
     assert not bad, bad[:8]
 
