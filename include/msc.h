@@ -210,6 +210,24 @@ int msc_softmax_fwd(const float* S, void* P, int64_t rows, int n, int ld, int dt
 int msc_softmax_bwd(const float* dP, const void* P, void* dS, int64_t rows, int n, int ld, int dtype,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * PPO loop around the path — device-side pieces; oracle: oracle/rl.py
+ * msc_gae: rewards/dones [T][N], values [T+1][N] (last row = bootstrap) -> adv, ret [T][N] (fp32, unfused arithmetic:
+ *   bit-exact against the oracle's recurrence).  msc_normalize: x <- (x-mean)/(std+eps), unbiased std, n <= 2^22.
+ * msc_sample_actions: inverse-CDF categorical sample per row of the policy head ([B][ld], logits 0..A-1, value at A)
+ *   with u = Philox4x32-10(counter = (row, step, 2), key = seed + seed_dev[0]); emits action, log pi(action), value. */
+int msc_gae(const float* rewards, const float* values, const float* dones, float* adv, float* ret, int T, int N,
+            float gamma, float lam, void* stream);
+int msc_normalize(float* x, int64_t n, float eps, void* stream);
+int msc_sample_actions(const void* head, int64_t* action, float* logp, float* value, int B, int A, int ld,
+                       uint64_t seed, const int64_t* seed_dev, uint64_t step, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Wire format of the semantic symbols — oracle: oracle/wire.py
+ * per frame: fp32 scale = amax/127 (1 if all zero) + k signed bytes I0,Q0,I1,Q1,..: q = clamp(rne(x/scale), -127, 127) */
+int msc_symbols_pack(const void* x, void* q, float* scale, int B, int k, int dtype, void* stream);
+int msc_symbols_unpack(const void* q, const float* scale, void* y, int B, int k, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,11 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 #define ATT_OOB 0x80000000u
 #define ATT_HD 64
+// ATT_ABLATE (tools/attn_ablate.py only; results are WRONG by construction), forward kernel:
+//   1 no K/V staging   2 no softmax arithmetic   3 no PV products / V reads   4 no QK products / K reads   5 no Q loads
+#ifndef ATT_ABLATE
+#define ATT_ABLATE 0
+#endif
 
 __device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 7; }              // ds_read_b128 on 128-B rows
 __device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 2; }         // ds_read_b64_tr_b16 only
@@ -104,8 +109,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
   const int NT = Tpad >> 5;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)0x7ffffff0, 0x00020000);
   const uint32_t row0 = (uint32_t)b * (uint32_t)T * (uint32_t)ld;
-  stage_image<true>(Kimg, rs, row0 + D + h * ATT_HD, ld, T, Tpad, nwaves);
-  stage_image<false>(Vimg, rs, row0 + 2 * D + h * ATT_HD, ld, T, Tpad, nwaves);
+  if (ATT_ABLATE != 1) {
+    stage_image<true>(Kimg, rs, row0 + D + h * ATT_HD, ld, T, Tpad, nwaves);
+    stage_image<false>(Vimg, rs, row0 + 2 * D + h * ATT_HD, ld, T, Tpad, nwaves);
+  }
 
   // this wave's two query tiles: B fragments (lane = query row) straight from HBM while the DMA is in flight
   bfx8 qf[2][4];
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
     qrow[t] = (2 * wave + t) * 32 + lr;
     const bf16_t* qp = qkv + ((long)b * T + (qrow[t] < T ? qrow[t] : 0)) * ld + h * ATT_HD;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[t][ks] = frag_global(qp, 2 * ks + lh, qrow[t] < T);
+    for (int ks = 0; ks < 4; ++ks) qf[t][ks] = frag_global(qp, 2 * ks + lh, ATT_ABLATE != 5 && qrow[t] < T);
   }
   f32x16_t oacc[2][2];
   float m[2], l[2];
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
       for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (ATT_ABLATE == 4) break;
       const bfx8 kf = frag_rows(Kimg, kt * 32 + lr, 2 * ks + lh);
       s[0] = MFMA(kf, qf[0][ks], s[0]);
       s[1] = MFMA(kf, qf[1][ks], s[1]);
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
     bfx8 pb[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      if (ATT_ABLATE == 2) { pb[t][0] = pack8(s[t], 0); pb[t][1] = pack8(s[t], 1); continue; }
       // VALU diet: the ragged-tail mask only on the last key tile (wave-uniform branch); the row maximum is taken on the
       // raw scores and scaled once (c_log2 > 0); scale and max-subtraction fold into one FMA per element below
       if (kt == NT - 1) {
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
+        if (ATT_ABLATE == 3) { oacc[0][dt][0] += (float)pb[0][sk][0]; oacc[1][dt][0] += (float)pb[1][sk][0]; continue; }
         const bfx8 vf = frag_tr_perm<false>(Vimg, kt * 32 + 16 * sk, dt * 32);
         oacc[0][dt] = MFMA(vf, pb[0][sk], oacc[0][dt]);
         oacc[1][dt] = MFMA(vf, pb[1][sk], oacc[1][dt]);

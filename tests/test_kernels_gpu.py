@@ -598,3 +598,72 @@ def test_linear_fp8_fwd_bwd(rts, dtype, M, N, K, act):
     check_grad("dx", xd.grad, xq.grad, tol(dtype) * 2, dtype, act == 1)
     check_grad("dw", W.g, lin.weight.grad, tol(dtype, True) * 4, dtype, act == 1)
     check_grad("db", Bp.g, lin.bias.grad, tol(dtype, True) * 4, dtype, act == 1)
+
+
+# ------------------------------------------------------------------------------------------------ PPO-loop kernels, wire format
+def test_gae_bit_exact(rts):
+    """msc_gae against oracle/rl.py: same fp32 recurrence, unfused -> bit-exact"""
+    import numpy as np
+    from oracle import rl as R
+    rt = rts["f32"]
+    T, N = 33, 130
+    g = torch.Generator().manual_seed(5)
+    rew, val = torch.randn(T, N, generator=g), torch.randn(T + 1, N, generator=g)
+    done = (torch.rand(T, N, generator=g) < 0.1).float()
+    adv, ret = torch.empty(T, N, device=rt.device), torch.empty(T, N, device=rt.device)
+    rt.call("msc_gae", rew.to(rt.device), val.to(rt.device), done.to(rt.device), adv, ret, T, N, 0.99, 0.95)
+    torch.cuda.synchronize()
+    oadv, oret = R.gae(rew.numpy(), val.numpy(), done.numpy(), 0.99, 0.95)
+    assert np.array_equal(adv.cpu().numpy(), oadv) and np.array_equal(ret.cpu().numpy(), oret)
+    x = adv.clone()
+    rt.call("msc_normalize", x, T * N, 1e-8)
+    check("normalize", x, torch.from_numpy(R.normalize(oadv)), 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sample_actions(rts, dtype):
+    """inverse-CDF sampling driven by Philox: actions bit-exact against oracle/rl.py on the logits the kernel sees,
+    log-probabilities within 1e-5, values passed through; the empirical distribution follows softmax(logits)."""
+    import numpy as np
+    from oracle import rl as R
+    rt = rts[dtype]
+    B, A, ld = 4096, 9, 16
+    head = rnd(B, ld, seed=3, scale=1.5)
+    hd_ = dev(head, rt)
+    act = torch.empty(B, dtype=torch.int64, device=rt.device)
+    logp, val = torch.empty(B, device=rt.device), torch.empty(B, device=rt.device)
+    seen = q(head, dtype)
+    for step in (0, 7, (1 << 33) + 5):
+        rt.call("msc_sample_actions", hd_, act, logp, val, B, A, ld, 1234, None, step, rt.dt)
+        torch.cuda.synchronize()
+        oa, ol = R.sample_actions(seen[:, :A].numpy(), 1234, step)
+        assert np.array_equal(act.cpu().numpy(), oa), (act.cpu().numpy() != oa).sum()
+        assert np.abs(logp.cpu().numpy() - ol).max() < 1e-5
+        assert torch.equal(val.cpu(), seen[:, A])
+    same = torch.zeros(B, ld)
+    same[:, :A] = torch.tensor([2.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0])
+    rt.call("msc_sample_actions", dev(same, rt), act, logp, val, B, A, ld, 99, None, 0, rt.dt)
+    freq = torch.bincount(act.cpu(), minlength=A).float() / B
+    assert (freq - torch.softmax(same[0, :A], 0)).abs().max() < 0.03
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_symbols_wire_format(rts, dtype):
+    """pack: bytes and scales bit-exact against oracle/wire.py (integer output); unpack o pack within half a step"""
+    import numpy as np
+    from oracle import wire as W
+    from multimodal_sc_amd.wire import pack_symbols, unpack_symbols, frame_bytes
+    rt = rts[dtype]
+    B, k = 67, 256
+    x = rnd(B, k, seed=8, scale=1.3)
+    x[3] = 0.0
+    x[4, 10] = 50.0
+    qd, sd = pack_symbols(rt, dev(x, rt))
+    y = unpack_symbols(rt, qd, sd)
+    torch.cuda.synchronize()
+    oq, os_ = W.pack(q(x, dtype).numpy())
+    assert np.array_equal(qd.cpu().numpy(), oq) and np.array_equal(sd.cpu().numpy(), os_)
+    ref = torch.from_numpy(W.unpack(oq, os_))
+    check("unpack", y, ref, tol(dtype))
+    assert (ref - q(x, dtype)).abs().max() <= 0.5 * os_.max() * 1.001
+    assert frame_bytes(k) == 260
