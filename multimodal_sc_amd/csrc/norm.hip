@@ -122,18 +122,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   if (ty < nty) {
-    for (long r = r0 + ty; r < r1; r += nty) {
-      const long e = r * C + tx * VEC;
-      vecf<T> vd, vx, vy;
-      vd.load(dy + e);
-      vx.load(x + e);
-      if (relu) vy.load(y + e);
+    // four rows per iteration, all their loads issued before the first use (the sums keep their row order)
+    for (long r = r0 + ty; r < r1; r += 4 * nty) {
+      vecf<T> vd[4], vx[4], vy[4];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float dz = vd.v[j];
-        if (relu && !(vy.v[j] > 0.f)) dz = 0.f;
-        s1[j] += dz;
-        s2[j] += dz * (vx.v[j] - mu[j]) * rs[j];
+      for (int u = 0; u < 4; ++u) {
+        const long ru = r + (long)u * nty;
+        if (ru < r1) {
+          const long e = ru * C + tx * VEC;
+          vd[u].load(dy + e);
+          vx[u].load(x + e);
+          if (relu) vy[u].load(y + e);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + (long)u * nty < r1) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float dz = vd[u].v[j];
+            if (relu && !(vy[u].v[j] > 0.f)) dz = 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (vx[u].v[j] - mu[j]) * rs[j];
+          }
+        }
       }
     }
   }
