@@ -14,6 +14,7 @@
 // Deterministic: every output element is produced by exactly one wave, no atomics.
 // Build-authored (the upstream reference has no code, SURVEY.md finding zero).  Role: FusionTransformer.
 #include "msc_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -27,7 +28,11 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define ATT_ABLATE 0
 #endif
 
-__device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 7; }              // ds_read_b128 on 128-B rows
+// Chunk swizzle of a 128-B-row image that is read BOTH by rows (ds_read_b128: the 8 even and 8 odd rows of a 16-lane
+// group must spread one chunk index over 8 distinct values -> a bijection of t = (row>>1)&7) AND transposed
+// (ds_read_b64_tr_b16: a 32-lane half reads 64 contiguous bytes of rows 4m..4m+3, so rows 4m and 4m+2 — same 256-B bank
+// window — must land in different 64-B halves -> bit 2 of the swizzle must be t's LOW bit).  f(t) = (t0 << 2) | (t >> 1).
+__device__ __forceinline__ int swz_row(int row) { return ((row & 2) << 1) | ((row >> 2) & 3); }
 __device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 2; }         // ds_read_b64_tr_b16 only
 
 // Stage rows [0,Tpad) x 64 columns of a bf16 matrix (element (r,c) at elem0 + r*ld + c) into an LDS image of 128-B rows.
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
 }
 
 // ================================================================================================ backward: dQ (+ delta)
-// wave w owns query tiles 2w, 2w+1 (one after the other); K and V panels resident in LDS.
+// wave w owns query tiles w, w+nwaves, ...; K and V panels resident in LDS.  (One wave per tile was tried: at ~190 VGPRs
+// per wave the extra waves only fit by spilling, and the kernel got slower.)
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, bf16_t* __restrict__ dqkv, int T, int Tpad,
@@ -222,14 +228,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int NT = Tpad >> 5;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)0x7ffffff0, 0x00020000);
   const uint32_t row0 = (uint32_t)b * (uint32_t)T * (uint32_t)ld;
-  stage_image<true>(Kimg, rs, row0 + D + h * ATT_HD, ld, T, Tpad, nwaves);
-  stage_image<true>(Vimg, rs, row0 + 2 * D + h * ATT_HD, ld, T, Tpad, nwaves);
+  if (ATT_ABLATE != 11) {
+    stage_image<true>(Kimg, rs, row0 + D + h * ATT_HD, ld, T, Tpad, nwaves);
+    stage_image<true>(Vimg, rs, row0 + 2 * D + h * ATT_HD, ld, T, Tpad, nwaves);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int t = 0; t < 2; ++t) {
-    const int qt = 2 * wave + t;
-    if (qt >= NT) break;
+  for (int qt = wave; qt < NT; qt += nwaves) {
     const int qrow = qt * 32 + lr;
     const bool qv = qrow < T;
     const long grow = (long)b * T + (qv ? qrow : 0);
@@ -257,11 +263,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+        if (ATT_ABLATE == 14) break;
         s = MFMA(frag_rows(Kimg, kt * 32 + lr, 2 * ks + lh), qf[ks], s);
         dp = MFMA(frag_rows(Vimg, kt * 32 + lr, 2 * ks + lh), gf[ks], dp);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if (ATT_ABLATE == 12) { s[r] += dp[r]; continue; }
         const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c_log2, -ls));
         s[r] = p * (dp[r] - dl);                        // dS^T
       }
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
       const bfx8 d0 = pack8(s, 0), d1 = pack8(s, 1);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
+        if (ATT_ABLATE == 13) { dq[dt][0] += (float)d0[0] + (float)d1[0]; continue; }
         dq[dt] = MFMA(frag_tr_perm<true>(Kimg, kt * 32, dt * 32), d0, dq[dt]);
         dq[dt] = MFMA(frag_tr_perm<true>(Kimg, kt * 32 + 16, dt * 32), d1, dq[dt]);
       }
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
 }
 
 // ================================================================================================ backward: dK, dV
-// wave w owns key tiles 2w, 2w+1 (one after the other); Q and dO panels resident in LDS (rows + transposed reads).
+// wave w owns key tiles w, w+nwaves, ...; Q and dO panels resident in LDS (rows + transposed reads).
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int T, int Tpad, int H, float c_log2, float scale) {
@@ -296,16 +305,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const int NT = Tpad >> 5;
   __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)0x7ffffff0, 0x00020000);
   __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, (int)0x7ffffff0, 0x00020000);
-  stage_image<true>(Qimg, rsq, (uint32_t)b * (uint32_t)T * (uint32_t)ld + h * ATT_HD, ld, T, Tpad, nwaves);
-  stage_image<true>(Gimg, rsg, (uint32_t)b * (uint32_t)T * (uint32_t)D + h * ATT_HD, D, T, Tpad, nwaves);
+  if (ATT_ABLATE != 11) {
+    stage_image<true>(Qimg, rsq, (uint32_t)b * (uint32_t)T * (uint32_t)ld + h * ATT_HD, ld, T, Tpad, nwaves);
+    stage_image<true>(Gimg, rsg, (uint32_t)b * (uint32_t)T * (uint32_t)D + h * ATT_HD, D, T, Tpad, nwaves);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float* lse_b = lse + (long)bh * Tpad;
   const float* del_b = delta + (long)bh * Tpad;
 
-  for (int t = 0; t < 2; ++t) {
-    const int kt = 2 * wave + t;
-    if (kt >= NT) break;
+  for (int kt = wave; kt < NT; kt += nwaves) {
     const int krow = kt * 32 + lr;
     const bool kvld = krow < T;
     const long grow = (long)b * T + (kvld ? krow : 0);
@@ -320,35 +329,53 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    // registers 4g..4g+3 of an S tile hold query rows qt*32 + 8g + 4lh + {0,1,2,3}: one 16-byte load each of lse and
+    // delta per g.  They come from HBM/L2, so the loads for tile qt+1 are issued before the products of tile qt
+    // (software prefetch, 32 VGPRs, issued right after the current tile's statistics were consumed): with two waves per SIMD nothing else would hide their latency.
+    float4 lnx[4], dnx[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      lnx[g] = *reinterpret_cast<const float4*>(lse_b + 8 * g + 4 * lh);
+      dnx[g] = *reinterpret_cast<const float4*>(del_b + 8 * g + 4 * lh);
+    }
     for (int qt = 0; qt < NT; ++qt) {
       f32x16_t s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+        if (ATT_ABLATE == 14) break;
         s = MFMA(frag_rows(Qimg, qt * 32 + lr, 2 * ks + lh), kf[ks], s);     // S[q][key]
         dp = MFMA(frag_rows(Gimg, qt * 32 + lr, 2 * ks + lh), vf[ks], dp);   // dP[q][key]
       }
       f32x16_t ds;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        // registers 4g..4g+3 hold query rows qt*32 + 8g + 4lh + {0,1,2,3}: one 16-byte load each of lse and delta
         const int q0 = qt * 32 + 8 * g + 4 * lh;
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_b + q0);
-        const float4 d4 = *reinterpret_cast<const float4*>(del_b + q0);
+        const float4 l4 = lnx[g];
+        const float4 d4 = dnx[g];
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           const bool ok = kvld && (q0 + e < T);   // padded rows of lse/delta hold garbage: never let it reach the math
+          if (ATT_ABLATE == 12) { ds[r] = s[r] + dp[r] + lv[e] + dvv[e]; continue; }
           const float p = ok ? __builtin_amdgcn_exp2f(s[r] * c_log2 - lv[e]) : 0.f;
           s[r] = p;
           ds[r] = ok ? p * (dp[r] - dvv[e]) : 0.f;
         }
       }
+      if (qt + 1 < NT) {   // next tile's statistics: in flight under the four products below and the next tile's S / dP
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          lnx[g] = *reinterpret_cast<const float4*>(lse_b + (qt + 1) * 32 + 8 * g + 4 * lh);
+          dnx[g] = *reinterpret_cast<const float4*>(del_b + (qt + 1) * 32 + 8 * g + 4 * lh);
+        }
+      }
       const bfx8 p0 = pack8(s, 0), p1 = pack8(s, 1), e0 = pack8(ds, 0), e1 = pack8(ds, 1);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
+        if (ATT_ABLATE == 13) { dv[dt][0] += (float)p0[0] + (float)p1[0]; dk[dt][0] += (float)e0[0] + (float)e1[0]; continue; }
         const bfx8 g0 = frag_tr_perm<true>(Gimg, qt * 32, dt * 32), g1 = frag_tr_perm<true>(Gimg, qt * 32 + 16, dt * 32);
         dv[dt] = MFMA(g0, p0, dv[dt]);
         dv[dt] = MFMA(g1, p1, dv[dt]);
@@ -399,9 +426,11 @@ extern "C" int msc_attention_bwd(const void* qkv, const void* o, const void* dou
   const size_t lds = (size_t)2 * Tpad * 128;
   hipStream_t st = (hipStream_t)stream;
   const float c = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(64 * nw), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
+  static int nwb_env = getenv("MSC_ATT_BWD_WAVES") ? atoi(getenv("MSC_ATT_BWD_WAVES")) : 0;   // tuning knob (A/B runs)
+  const int nwb = nwb_env > 0 ? (nwb_env > 8 ? 8 : nwb_env) : nw;   // <= 8 waves: the kernels need ~190 VGPRs (two waves per SIMD)
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(64 * nwb), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                      delta, (bf16_t*)dqkv, T, Tpad, H, c, scale);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(64 * nw), lds, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(64 * nwb), lds, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
                      (bf16_t*)dqkv, T, Tpad, H, c, scale);
   return msc_launch_status();
 }

@@ -5,7 +5,8 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = os.path.join(ROOT, "tools", "abl")
 CSRC = os.path.join(ROOT, "multimodal_sc_amd", "csrc")
-NAMES = {0: "baseline", 1: "no K/V staging", 2: "no softmax", 3: "no PV", 4: "no QK", 5: "no Q loads"}
+NAMES = {0: "baseline", 1: "fwd: no K/V staging", 2: "fwd: no softmax", 3: "fwd: no PV", 4: "fwd: no QK", 5: "fwd: no Q loads",
+         11: "bwd: no staging", 12: "bwd: no exp/VALU", 13: "bwd: no 2nd-stage MFMA", 14: "bwd: no 1st-stage MFMA"}
 
 
 def build():
@@ -35,7 +36,25 @@ def child(n):
     o = torch.empty(B * T, D, device=rt.device, dtype=torch.bfloat16)
     Tp = L.query("msc_attention_tpad", T)
     lse = torch.empty(B * H * Tp, device=rt.device)
-    fn = lambda: rt.call("msc_attention_fwd", qkv, o, lse, B, T, H, 64, 0.125, rt.dt)
+    do = (torch.randn(B * T, D, device=rt.device) * 0.5).to(torch.bfloat16)
+    dqkv, delta = torch.empty_like(qkv), torch.empty_like(lse)
+    rt.call("msc_attention_fwd", qkv, o, lse, B, T, H, 64, 0.125, rt.dt)
+    if n >= 10:
+        fn = lambda: rt.call("msc_attention_bwd", qkv, o, do, lse, delta, dqkv, B, T, H, 64, 0.125, rt.dt)
+    else:
+        fn = lambda: rt.call("msc_attention_fwd", qkv, o, lse, B, T, H, 64, 0.125, rt.dt)
+    if n == 0:
+        fb = lambda: rt.call("msc_attention_bwd", qkv, o, do, lse, delta, dqkv, B, T, H, 64, 0.125, rt.dt)
+        for _ in range(3):
+            fb()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fb()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"bwd baseline {e0.elapsed_time(e1) / 50 * 1e3:.1f} us", file=sys.stderr)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -52,7 +71,7 @@ def main():
     for n in NAMES:
         o = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(n)], capture_output=True, text=True, timeout=300)
         t = [ln.split("|")[2] for ln in o.stdout.splitlines() if ln.startswith("RES|")]
-        print(f"{NAMES[n]:20s} {t[0] if t else 'FAILED ' + o.stderr[-300:]} us")
+        print(f"{NAMES[n]:26s} {t[0] if t else 'FAILED ' + o.stderr[-300:]} us   {o.stderr.strip().splitlines()[-1] if n == 0 and o.stderr.strip() else ''}")
 
 
 if __name__ == "__main__":
