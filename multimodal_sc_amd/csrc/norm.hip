@@ -122,30 +122,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   if (ty < nty) {
-    // four rows per iteration, all their loads issued before the first use (the sums keep their row order)
-    for (long r = r0 + ty; r < r1; r += 4 * nty) {
-      vecf<T> vd[4], vx[4], vy[4];
+    for (long r = r0 + ty; r < r1; r += nty) {
+      const long e = r * C + tx * VEC;
+      vecf<T> vd, vx, vy;
+      vd.load(dy + e);
+      vx.load(x + e);
+      if (relu) vy.load(y + e);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long ru = r + (long)u * nty;
-        if (ru < r1) {
-          const long e = ru * C + tx * VEC;
-          vd[u].load(dy + e);
-          vx[u].load(x + e);
-          if (relu) vy[u].load(y + e);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (r + (long)u * nty < r1) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float dz = vd[u].v[j];
-            if (relu && !(vy[u].v[j] > 0.f)) dz = 0.f;
-            s1[j] += dz;
-            s2[j] += dz * (vx[u].v[j] - mu[j]) * rs[j];
-          }
-        }
+      for (int j = 0; j < VEC; ++j) {
+        float dz = vd.v[j];
+        if (relu && !(vy.v[j] > 0.f)) dz = 0.f;
+        s1[j] += dz;
+        s2[j] += dz * (vx.v[j] - mu[j]) * rs[j];
       }
     }
   }
@@ -210,40 +198,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   constexpr int VEC = msc_traits<T>::VEC;
   constexpr int MAXIT = LN_MAXC / VEC;
   const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
   const int nit = D / (64 * VEC);
-  // two rows per wave, both rows' loads issued before either reduction: twice the bytes in flight per wave
-  const long rowa = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
-  if (rowa >= rows) return;
-  const bool two = rowa + 1 < rows;
-  vecf<T> v[2][MAXIT];
-  float s[2] = {0.f, 0.f};
+  vecf<T> v[MAXIT];
+  float s = 0.f;
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      v[it].load(x + row * D + (it * 64 + lane) * VEC);
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
-      if (it < nit) {
-        if (r == 0 || two) v[r][it].load(x + (rowa + r) * D + (it * 64 + lane) * VEC);
-        else {
+      for (int j = 0; j < VEC; ++j) s += v[it].v[j];
+    }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) v[r][it].v[j] = 0.f;
-        }
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) s[r] += v[r][it].v[j];
-      }
-  float mu[2], rs[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) mu[r] = wave_sum(s[r]) / (float)D;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    float q = 0.f;
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
-      if (it < nit) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { const float d = v[r][it].v[j] - mu[r]; q += d * d; }
-      }
-    rs[r] = rsqrtf(wave_sum(q) / (float)D + eps);
-  }
+      for (int j = 0; j < VEC; ++j) { const float d = v[it].v[j] - mu; q += d * d; }
+    }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it)
     if (it < nit) {
@@ -252,17 +227,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       ldc<VEC>(gamma + c0, g);
       ldc<VEC>(beta + c0, b);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        if (r == 1 && !two) break;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) v[r][it].v[j] = (v[r][it].v[j] - mu[r]) * rs[r] * g[j] + b[j];
-        v[r][it].store(y + (rowa + r) * D + c0);
-      }
+      for (int j = 0; j < VEC; ++j) v[it].v[j] = (v[it].v[j] - mu) * rs * g[j] + b[j];
+      v[it].store(y + row * D + c0);
     }
-  if (lane == 0) {
-    mean[rowa] = mu[0]; rstd[rowa] = rs[0];
-    if (two) { mean[rowa + 1] = mu[1]; rstd[rowa + 1] = rs[1]; }
-  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
 // block = 4 waves, LN_ROWS_PER_BLOCK rows (each wave takes every 4th); each lane owns D/64 columns
@@ -287,70 +255,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int j = 0; j < VEC; ++j) { dg[it * VEC + j] = 0.f; db[it * VEC + j] = 0.f; ga[it * VEC + j] = g[j]; }
   }
   const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
-  // each wave takes rows wave, wave+4, ... of the block, TWO at a time with every load (dy, x, dadd) of both rows issued
-  // before the first reduction: the kernel is latency-bound otherwise (one 1-KiB row per wave in flight)
-  for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 8) {
-    long rowv[2] = {r0 + rr, r0 + rr + 4};
-    bool okv[2] = {rowv[0] < rows, rr + 4 < LN_ROWS_PER_BLOCK && rowv[1] < rows};
-    if (!okv[0]) break;
-    vecf<T> vd[2][MAXIT], vx[2][MAXIT], va[2][MAXIT];
-    float mu[2], rs[2];
+  for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 4) {
+    const long row = r0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    vecf<T> vd[MAXIT], vx[MAXIT];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      mu[r] = okv[r] ? mean[rowv[r]] : 0.f;
-      rs[r] = okv[r] ? rstd[rowv[r]] : 0.f;
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int c0 = (it * 64 + lane) * VEC;
+        vd[it].load(dy + row * D + c0);
+        vx[it].load(x + row * D + c0);
 #pragma unroll
-      for (int it = 0; it < MAXIT; ++it)
-        if (it < nit) {
-          const int c0 = (it * 64 + lane) * VEC;
-          if (okv[r]) {
-            vd[r][it].load(dy + rowv[r] * D + c0);
-            vx[r][it].load(x + rowv[r] * D + c0);
-            if (dadd) va[r][it].load(dadd + rowv[r] * D + c0);
-          } else {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) { vd[r][it].v[j] = 0.f; vx[r][it].v[j] = 0.f; }
-          }
+        for (int j = 0; j < VEC; ++j) {
+          const float xh = (vx[it].v[j] - mu) * rs;
+          const float g = vd[it].v[j] * ga[it * VEC + j];
+          vx[it].v[j] = xh;
+          s1 += g;
+          s2 += g * xh;
+          dg[it * VEC + j] += vd[it].v[j] * xh;
+          db[it * VEC + j] += vd[it].v[j];
         }
-    }
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+      }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int c0 = (it * 64 + lane) * VEC;
+        vecf<T> va;
+        if (dadd) va.load(dadd + row * D + c0);
 #pragma unroll
-      for (int it = 0; it < MAXIT; ++it)
-        if (it < nit) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            const float xh = (vx[r][it].v[j] - mu[r]) * rs[r];
-            const float g = vd[r][it].v[j] * ga[it * VEC + j];
-            vx[r][it].v[j] = xh;
-            s1[r] += g;
-            s2[r] += g * xh;
-            dg[it * VEC + j] += vd[r][it].v[j] * xh;
-            db[it * VEC + j] += vd[r][it].v[j];
-          }
+        for (int j = 0; j < VEC; ++j) {
+          float o = rs * (vd[it].v[j] * ga[it * VEC + j] - s1 - vx[it].v[j] * s2);
+          if (dadd) o += va.v[j];
+          vx[it].v[j] = o;
         }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      s1[r] = wave_sum(s1[r]) / (float)D;
-      s2[r] = wave_sum(s2[r]) / (float)D;
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (!okv[r]) continue;
-#pragma unroll
-      for (int it = 0; it < MAXIT; ++it)
-        if (it < nit) {
-          const int c0 = (it * 64 + lane) * VEC;
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float o = rs[r] * (vd[r][it].v[j] * ga[it * VEC + j] - s1[r] - vx[r][it].v[j] * s2[r]);
-            if (dadd) o += va[r][it].v[j];
-            vx[r][it].v[j] = o;
-          }
-          vx[r][it].store(dx + rowv[r] * D + c0);
-        }
-    }
+        vx[it].store(dx + row * D + c0);
+      }
   }
   // cross-wave reduce of dgamma/dbeta, then one partial row per block
   __shared__ float red[2][4][1024];
@@ -527,7 +470,7 @@ extern "C" int msc_layernorm_fwd(const void* x, const float* gamma, const float*
                                  float* rstd, int64_t rows, int D, float eps, int dtype, void* stream) {
   MSC_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0 && D <= 1024);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)cdiv(rows, 8);   // 4 waves x 2 rows
+  const unsigned grid = (unsigned)cdiv(rows, 4);
   if (dtype == MSC_F32) {
     MSC_CHECK_ARG(D % 256 == 0);
     hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y,
