@@ -9,6 +9,7 @@ convert.  Nothing in this file runs math on the CPU or through torch ops: every 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -140,6 +141,9 @@ class MultimodalSC:
         self.rt = Runtime(dtype, device)
         self.params = ParamStore(self.rt, param_specs(cfg))
         self.anchor = torch.zeros(1, device=self.rt.device, requires_grad=True)
+        self._img_cut = int(os.environ.get("MSC_IMG_CUT", "3"))   # trunk layers below the backward boundary (0 = none)
+        self._img_cut_out = self._img_cut_in = None
+        self._bev_slot = None
         self.channel_seed = 0
         self._init_params(seed)
 
@@ -221,7 +225,13 @@ class MultimodalSC:
         x = F.ConvBNAct.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
                               P["image_encoder.bn1.bias"], 2, 3, True, False)
         x = F.MaxPool.apply(x, rt, 3, 2, 1)
+        self._img_cut_out = self._img_cut_in = None
         for li in range(1, 5):
+            if li == self._img_cut + 1 and self.cfg.use_lidar and rt.branch_streams and x.requires_grad:
+                # autograd boundary inside the trunk: backward_lower() runs the layers above it FIRST, so the main stream
+                # has work queued while the host enqueues the whole BEV-branch backward (see backward_lower)
+                self._img_cut_out = x
+                x = self._img_cut_in = x.detach().requires_grad_()
             for bi in range(2):
                 has_ds = bi == 0 and li > 1
                 x = F.BasicBlockFn.apply(x, rt, self._block_params(f"image_encoder.layer{li}.{bi}", has_ds), 2 if has_ds else 1)
@@ -335,10 +345,18 @@ class MultimodalSC:
         rt = self.rt
         outs, grads = self._enc_out, [t.grad for t in self._enc_in]
         if self._bev_slot is not None and rt._branch is not None:
-            # autograd would replay the branch whose forward was recorded first (BEV) LAST, i.e. enqueue it behind the whole
-            # ResNet backward and leave it as a ~1 ms tail on an otherwise idle chip: enqueue it first, on its own stream
-            # (with the branch stream current: the engine ends a backward by making the CALLER's stream wait for every
-            # stream it used, which would stall the main stream for the whole BEV backward)
+            # Order of enqueueing (the host, not the GPU, paces this part):
+            #  1. the top of the camera trunk (above the boundary image_encoder() left) on the main stream — ~0.5 ms of GPU
+            #     work the main stream chews on while
+            #  2. the host enqueues the whole BEV-branch backward on ITS stream.  autograd alone would replay the branch
+            #     whose forward was recorded first (BEV) LAST — a ~1 ms tail on an otherwise idle chip.  The branch stream
+            #     is made current for that call: the engine ends a backward by making the CALLER's stream wait for every
+            #     stream it used, which would stall the main stream for the whole BEV backward.
+            #  3. the rest of the camera trunk and the state encoder.
+            if self._img_cut_in is not None:
+                torch.autograd.backward([outs[0]], [grads[0]])
+                outs, grads = [self._img_cut_out] + outs[1:], [self._img_cut_in.grad] + grads[1:]
+                self._img_cut_out = self._img_cut_in = None
             i = self._bev_slot
             main, s2 = torch.cuda.current_stream(rt.device), rt._branch
             s2.wait_stream(main)
