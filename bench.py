@@ -25,6 +25,23 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
+def pmc_hbm_bytes_per_gemm_launch():
+    """HBM bytes per launch of the contraction kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, separate passes over this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM;
+    tools/pmc_hbm_summary.py).  Counters cannot be read from inside the timed process, so the figure comes from the profile
+    file; None when it is absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_bench_c3.csv")
+    if not os.path.exists(path):
+        return None, None
+    b = n = 0.0
+    for r in csv.DictReader(open(path)):
+        if "gemm_kernel<unsigned short" in r["kernel"]:
+            b += float(r["fetch_bytes_corrected_x2"]) + float(r["write_bytes"])
+            n += int(r["calls"])
+    return (b / n if n else None), "profiles/r1_pmc_hbm_bench_c3.csv"
+
+
 def gemm_flops(name, s):
     """algorithmic FLOPs of one C-ABI GEMM-family call from its scalar arguments (see Runtime.call)."""
     def conv(B, H, W, Cin, Cout, KH, KW, st, p):
@@ -177,8 +194,10 @@ def main():
                 n_gemm += 1
         rt.profile = None
         achieved = gemm_f / (gemm_t * 1e-3) / 1e12
+        traffic, traffic_src = pmc_hbm_bytes_per_gemm_launch()
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_kernel<bf16,*>",
+                              "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                              "traffic_source": traffic_src, "kernel": "gemm_kernel<bf16,*>",
                               "launches_per_step": n_gemm, "algorithmic_gflop_per_step": gemm_f / 1e9, "kernel_ms_per_step": gemm_t}
         result["breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 
