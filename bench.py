@@ -63,6 +63,31 @@ def gemm_flops(name, s):
     return None
 
 
+def gemm_bytes(name, s):
+    """algorithmic HBM bytes of the same calls: every operand read once, the output written once (bf16 activations /
+    compute weights, fp32 weight gradients); what `roofline.traffic` is to be compared with."""
+    def conv(B, H, W, Cin, Cout, KH, KW, st, p, wbytes):
+        Ho, Wo = (H + 2 * p - KH) // st + 1, (W + 2 * p - KW) // st + 1
+        return 2.0 * B * H * W * Cin + 2.0 * B * Ho * Wo * Cout + wbytes * Cout * KH * KW * Cin
+    if name in ("msc_conv2d_fwd", "msc_conv2d_dgrad"):
+        return conv(*s[:9], 2.0)
+    if name == "msc_conv2d_wgrad":
+        return conv(*s[1:10], 4.0)
+    if name == "msc_linear_fwd":
+        M, N, K = s[0], s[1], s[2]
+        return 2.0 * (M * K + N * K + M * N)
+    if name == "msc_linear_dgrad":
+        M, N, K = s[1], s[2], s[3]
+        return 2.0 * (M * K + N * K + M * N)
+    if name == "msc_linear_wgrad":
+        M, N, K = s[1], s[2], s[3]
+        return 2.0 * (M * K + M * N) + 4.0 * N * K
+    if name == "msc_gemm_batched":
+        M, N, K, z = s[0], s[1], s[2], s[8]
+        return 2.0 * z * (M * K + N * K + M * N)
+    return None
+
+
 def cpu_baseline(cfg_name, seconds_budget=20.0):
     """oracle fwd+bwd (fp32, all host threads) on a bounded sample of the same workload -> frames/s"""
     import torch
@@ -180,7 +205,7 @@ def main():
         model.params.adam_step(lr=1e-4)
         torch.cuda.synchronize()
         by = {}
-        gemm_t = gemm_f = 0.0
+        gemm_t = gemm_f = gemm_b = 0.0
         n_gemm = 0
         for name, s, e0, e1 in rt.profile:
             ms = e0.elapsed_time(e1)
@@ -191,13 +216,15 @@ def main():
             if f is not None:
                 gemm_t += ms
                 gemm_f += f
+                gemm_b += gemm_bytes(name, s)
                 n_gemm += 1
         rt.profile = None
         achieved = gemm_f / (gemm_t * 1e-3) / 1e12
         traffic, traffic_src = pmc_hbm_bytes_per_gemm_launch()
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                              "traffic_source": traffic_src, "kernel": "gemm_kernel<bf16,*>",
+                              "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gemm_b / max(n_gemm, 1),
+                              "kernel": "gemm_kernel<bf16,*>",
                               "launches_per_step": n_gemm, "algorithmic_gflop_per_step": gemm_f / 1e9, "kernel_ms_per_step": gemm_t}
         result["breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 

@@ -40,6 +40,7 @@ struct GemmParams {
   // geometry of the gathered NHWC tensor (conv modes)
   int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
   int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
+  int xcd_split;                // split-K launches: all tiles of one K slice on one XCD (see the kernel's index mapping)
   const void* dref; int dact;   // epilogue: multiply by act'(dref[m][n]) (fused activation backward)
   float* colsum;                // epilogue: per-row-block column sums of the stored output, [tile_m][N]
 };
@@ -297,10 +298,24 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest, then z).  Plain launches: tiles sharing an
+  // activation row block on one XCD (xcd_remap).  Split-K launches with nsplit % 8 == 0 (weight gradients): ALL tiles of
+  // one K slice on one XCD — they stream the same rows of both operands at the same time, so the slice is fetched into
+  // that L2 once instead of once per tile (PMC: weight-gradient HBM/fabric traffic was ~4x the algorithmic bytes).
+  int bid, zz, split;
+  if (p.xcd_split) {
+    const int L = blockIdx.z * gridDim.x + blockIdx.x;
+    const int q = L >> 3;
+    split = (L & 7) + 8 * (q / (int)gridDim.x);
+    bid = q % (int)gridDim.x;
+    zz = 0;
+  } else {
+    bid = xcd_remap(blockIdx.x, gridDim.x);
+    zz = blockIdx.z / p.nsplit;
+    split = blockIdx.z % p.nsplit;
+  }
   const int tile_m = bid / ntn, tile_n = bid % ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int zz = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
   const int zo = zz / p.batch_inner, zi = zz % p.batch_inner;
 
   const T* Ab = reinterpret_cast<const T*>(p.A) + zo * p.sa_o + zi * p.sa_i;
@@ -770,6 +785,13 @@ static int plan_split(long rows_out, long cols_out, long reduce_len) {
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   if (want > 128) want = 128;
+  // multiples of 8 let the kernel pin each K slice to one XCD (xcd_split)
+  static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;   // A/B knob
+  if (xs && want >= 6) {
+    long w8 = (want + 4) / 8 * 8;
+    if (w8 > cap) w8 = cap / 8 * 8;
+    if (w8 >= 8) want = w8;
+  }
   return (int)want;
 }
 
@@ -788,6 +810,8 @@ static int finish_wgrad(GemmParams& p, float* dw, float* ws, int64_t ws_bytes, l
   if (((long)p.M * p.N) % 4) return MSC_ERR_BAD_ARG;
   p.nsplit = ns;
   p.tiles_per_split = tps;
+  static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;
+  p.xcd_split = (xs && ns >= 8 && ns % 8 == 0) ? 1 : 0;
   p.C = ws;
   p.ldc = p.N;
   p.out_f32 = 1;
