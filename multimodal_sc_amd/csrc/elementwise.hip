@@ -13,6 +13,20 @@ template <typename T>
 __global__ void image_to_nhwc_kernel(const float* __restrict__ img, T* __restrict__ out, long npix_total, int C, long HW, int Cpad) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix_total; i += (long)gridDim.x * blockDim.x) {
     const long b = i / HW, pix = i % HW;
+    if (Cpad == 8 && C <= 8) {   // the stem's layout: one pixel = 8 channels = one (bf16) or two (f32) 16-byte stores
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = c < C ? img[(b * C + c) * HW + pix] : 0.f;
+      constexpr int VEC = msc_traits<T>::VEC;
+#pragma unroll
+      for (int c0 = 0; c0 < 8; c0 += VEC) {
+        vecf<T> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = v[c0 + j];
+        o.store(out + i * 8 + c0);
+      }
+      continue;
+    }
     for (int c = 0; c < Cpad; ++c) {
       const float v = c < C ? img[(b * C + c) * HW + pix] : 0.f;
       msc_traits<T>::st(out + i * Cpad + c, v);
@@ -28,11 +42,12 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
   const int cv = C / VEC;
   const long n = (long)B * Ho * Wo * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cv) * VEC;
-    long t = i / cv;
-    const int wo = (int)(t % Wo); t /= Wo;
-    const int ho = (int)(t % Ho);
-    const int b = (int)(t / Ho);
+    const unsigned iu = (unsigned)i;   // n < 2^31 (launcher): 32-bit divisions
+    const int c0 = (int)(iu % (unsigned)cv) * VEC;
+    unsigned t = iu / (unsigned)cv;
+    const int wo = (int)(t % (unsigned)Wo); t /= (unsigned)Wo;
+    const int ho = (int)(t % (unsigned)Ho);
+    const int b = (int)(t / (unsigned)Ho);
     float best[VEC];
     int bi[VEC];
 #pragma unroll
@@ -67,11 +82,13 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
   const int cv = C / VEC;
   const long n = (long)B * H * W * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cv) * VEC;
-    long t = i / cv;
-    const int w = (int)(t % W); t /= W;
-    const int h = (int)(t % H);
-    const int b = (int)(t / H);
+    // 32-bit index arithmetic (n < 2^31 is checked by the launcher): 64-bit divisions dominated this kernel
+    const unsigned iu = (unsigned)i;
+    const int c0 = (int)(iu % (unsigned)cv) * VEC;
+    unsigned t = iu / (unsigned)cv;
+    const int w = (int)(t % (unsigned)W); t /= (unsigned)W;
+    const int h = (int)(t % (unsigned)H);
+    const int b = (int)(t / (unsigned)H);
     vecf<T> acc;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
@@ -88,9 +105,14 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
         const long oo = (((long)b * Ho + ho) * Wo + wo) * C + c0;
         vecf<T> g;
         g.load(dy + oo);
+        // the VEC tap ids of this window in one load (oo is a multiple of VEC)
+        uint64_t taps;
+        if constexpr (VEC == 8) taps = *reinterpret_cast<const uint64_t*>(idx + oo);
+        else taps = *reinterpret_cast<const uint32_t*>(idx + oo);
+        const unsigned want = (unsigned)(kh * K + kw);
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-          if (idx[oo + j] == kh * K + kw) acc.v[j] += g.v[j];
+          if (((taps >> (8 * j)) & 0xffu) == want) acc.v[j] += g.v[j];
       }
     }
     acc.store(dx + (((long)b * H + h) * W + w) * C + c0);
@@ -141,28 +163,55 @@ __global__ void tokens_split_kernel(const T* __restrict__ dout, T* __restrict__ 
 }
 
 // ---------------------------------------------------------------- mean over tokens
+// block = (D/VEC column vectors, <= 64) x TG token groups for ONE batch row-block; thread (cx, g) sums tokens g, g+TG, ...
+// with four independent accumulators (the loop is latency-bound otherwise: 306 dependent loads per thread), then the
+// groups are combined through LDS in the order 0..TG-1 (fixed order: reproducible).
+#define MEANPOOL_TG 16
 template <typename T>
-__global__ void meanpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Tt, int D) {
+__global__ __launch_bounds__(64 * MEANPOOL_TG) void meanpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Tt, int D) {
   constexpr int VEC = msc_traits<T>::VEC;
+  __shared__ float red[MEANPOOL_TG][64][VEC];
   const int dv = D / VEC;
-  const long n = (long)B * dv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int d0 = (int)(i % dv) * VEC;
-    const long b = i / dv;
-    float s[VEC];
+  const int cx = threadIdx.x, g = threadIdx.y;
+  const int cblk = (dv + 63) / 64;
+  const long b = blockIdx.x / cblk;
+  const int c = (blockIdx.x % cblk) * 64 + cx;
+  float s[4][VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
-    for (int t = 0; t < Tt; ++t) {
-      vecf<T> v;
-      v.load(x + ((b * Tt + t) * D + d0));
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) s[j] += v.v[j];
+    for (int j = 0; j < VEC; ++j) s[u][j] = 0.f;
+  if (c < dv) {
+    const T* base = x + (b * Tt) * D + c * VEC;
+    int t = g;
+    for (; t + 3 * MEANPOOL_TG < Tt; t += 4 * MEANPOOL_TG) {
+      vecf<T> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u].load(base + (long)(t + u * MEANPOOL_TG) * D);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[u][j] += v[u].v[j];
     }
-    vecf<T> o;
+    for (; t < Tt; t += MEANPOOL_TG) {
+      vecf<T> v;
+      v.load(base + (long)t * D);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o.v[j] = s[j] / (float)Tt;
-    o.store(y + b * D + d0);
+      for (int j = 0; j < VEC; ++j) s[0][j] += v.v[j];
+    }
   }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[g][cx][j] = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
+  __syncthreads();
+  if (g != 0 || c >= dv) return;
+  vecf<T> o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float a = red[0][cx][j];
+    for (int r = 1; r < MEANPOOL_TG; ++r) a += red[r][cx][j];
+    o.v[j] = a / (float)Tt;
+  }
+  o.store(y + b * D + c * VEC);
 }
 template <typename T>
 __global__ void meanpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Tt, int D) {
@@ -300,7 +349,7 @@ extern "C" int msc_image_to_nhwc(const float* img_nchw, void* out, int B, int C,
 
 extern "C" int msc_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int K, int S, int P, int dtype, void* stream) {
   MSC_CHECK_ARG(x && y && idx && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && K * K <= 255 && S > 0 && P >= 0 && P < K);
-  MSC_CHECK_ARG(C % (dtype == MSC_F32 ? 4 : 8) == 0);
+  MSC_CHECK_ARG(C % (dtype == MSC_F32 ? 4 : 8) == 0 && (long)B * H * W * C < 0x7fffffffL);
   const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_blocks((long)B * Ho * Wo * C / msc_traits<T>::VEC)), dim3(256), 0,
                                        (hipStream_t)stream, (const T*)x, (T*)y, idx, B, H, W, C, Ho, Wo, K, S, P));
@@ -309,7 +358,7 @@ extern "C" int msc_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int 
 
 extern "C" int msc_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int K, int S, int P, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && dx && idx && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && S > 0 && P >= 0 && P < K);
-  MSC_CHECK_ARG(C % (dtype == MSC_F32 ? 4 : 8) == 0);
+  MSC_CHECK_ARG(C % (dtype == MSC_F32 ? 4 : 8) == 0 && (long)B * H * W * C < 0x7fffffffL);
   const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_blocks((long)B * H * W * C / msc_traits<T>::VEC)), dim3(256), 0,
                                        (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, H, W, C, Ho, Wo, K, S, P));
@@ -336,8 +385,8 @@ extern "C" int msc_tokens_split(const void* dout, void* d0, void* d1, void* d2, 
 
 extern "C" int msc_meanpool_fwd(const void* x, void* y, int B, int Tt, int D, int dtype, void* stream) {
   MSC_CHECK_ARG(x && y && B > 0 && Tt > 0 && D > 0 && D % (dtype == MSC_F32 ? 4 : 8) == 0);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(meanpool_fwd_kernel<T>, dim3(ew_blocks((long)B * D / msc_traits<T>::VEC, 64)), dim3(64), 0, (hipStream_t)stream,
-                                       (const T*)x, (T*)y, B, Tt, D));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(meanpool_fwd_kernel<T>, dim3((unsigned)(B * ((D / msc_traits<T>::VEC + 63) / 64))), dim3(64, MEANPOOL_TG), 0,
+                                       (hipStream_t)stream, (const T*)x, (T*)y, B, Tt, D));
   return msc_launch_status();
 }
 extern "C" int msc_meanpool_bwd(const void* dy, void* dx, int B, int Tt, int D, int dtype, void* stream) {

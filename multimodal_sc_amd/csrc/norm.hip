@@ -83,9 +83,14 @@ template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                 const T* __restrict__ res, T* __restrict__ y, long nvec, int C, int relu) {
   constexpr int VEC = msc_traits<T>::VEC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+  // channel of the vector, kept incrementally: a 64-bit modulo per 16-byte vector costs more than the rest of the body
+  const unsigned ncv = (unsigned)C / VEC;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  unsigned cvi = (unsigned)(i0 % ncv);
+  const unsigned cstep = (unsigned)(stride % ncv);
+  for (long i = i0; i < nvec; i += stride, cvi = cvi + cstep >= ncv ? cvi + cstep - ncv : cvi + cstep) {
     const long e = i * VEC;
-    const int c0 = (int)(e % C);
+    const int c0 = (int)(cvi * VEC);
     vecf<T> vx, vr;
     vx.load(x + e);
     if (res) vr.load(res + e);
