@@ -285,8 +285,18 @@ __global__ void permute3_cast_kernel(const float* __restrict__ src, T* __restric
 template <typename T>
 __global__ void permute3_cast_batched_kernel(const float* __restrict__ P, T* __restrict__ TR, const int64_t* __restrict__ table, int n) {
   __shared__ float tile[32][33];
-  int e = 0;
-  while (e + 1 < n && (long)blockIdx.x >= table[(e + 1) * 6 + 5]) ++e;
+  __shared__ int s_e;
+  // which table entry owns this block: every lane of wave 0 tests entries lane, lane+64, ... at once (a serial walk of
+  // the ~60 entries was ~60 dependent loads at the head of every block)
+  if (threadIdx.x < 64) {
+    int cnt = 0;
+    for (int t = threadIdx.x; t < n; t += 64) cnt += ((long)blockIdx.x >= table[t * 6 + 5]) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (threadIdx.x == 0) s_e = cnt - 1;     // first_block is ascending and starts at 0
+  }
+  __syncthreads();
+  const int e = s_e;
   const int64_t* d = table + e * 6;
   const float* src = P + d[0];
   T* dst = TR + d[1];
