@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // block = 4 waves, LN_ROWS_PER_BLOCK rows (each wave takes every 4th); each lane owns D/64 columns
-#define LN_ROWS_PER_BLOCK 16
+#ifndef LN_ROWS_PER_BLOCK
+#define LN_ROWS_PER_BLOCK 32
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
