@@ -171,6 +171,7 @@ class MultimodalSC:
 
     def load_oracle_state_dict(self, sd):
         """sd: state_dict of oracle.model.MultimodalSC (or any dict with the same keys/shapes, OIHW convs)."""
+        self.rt.join_side()      # a pending side-stream optimizer update must not overwrite what is loaded here
         A = self.cfg.n_actions
         for r in self.params.refs.values():
             if r.name == "head.out.weight":
@@ -192,6 +193,7 @@ class MultimodalSC:
 
     def export_state_dict(self, grads: bool = False):
         """Back to the oracle's key names / OIHW layout (parameters, or their gradients with grads=True)."""
+        self.rt.join_side()      # weight gradients and the upper half of the optimizer update run on the side stream
         A = self.cfg.n_actions
         out = {}
         for r in self.params.refs.values():
@@ -304,6 +306,7 @@ class MultimodalSC:
         img_tok = next(it)
         bev_tok = next(it) if bev_tok is not None else None
         st_tok = next(it) if st_tok is not None else None
+        rt.join_side()     # a side-stream Adam update of the transformer / codec / head parameters (Trainer) must have landed
         x = self.fusion(img_tok, bev_tok, st_tok)
         f = F.MeanPool.apply(x, rt)
         sym = self._lin(self._lin(f, "semantic_encoder.fc1", L.ACT_RELU), "semantic_encoder.fc2")

@@ -166,36 +166,67 @@ class ParamStore:
         self.step_count = 0
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # device-side step counter (hipGraph replay)
         self._ptable = None
+        self._ptable_split = None
 
     def __getitem__(self, name) -> ParamRef:
         return self.refs[name]
+
+    def _tables(self, split):
+        """descriptor tables of the weight transposes (one launch instead of one per weight): all / below split / above split"""
+        if self._ptable is None or self._ptable_split != split:
+            def build(lo, hi):
+                rows, blk = [], 0
+                for r in self.refs.values():
+                    if r.kind == "conv":
+                        d0, d1, d2 = r.shape[0], r.shape[1] * r.shape[2], r.shape[3]
+                    elif r.kind == "linear":
+                        d0, d1, d2 = r.shape[0], 1, r.shape[1]
+                    else:
+                        continue
+                    if not (lo <= r.off < hi):
+                        continue
+                    rows.append([r.off, r.off, d0, d1, d2, blk])
+                    blk += ((d2 + 31) // 32) * ((d0 + 31) // 32) * d1
+                t = torch.tensor(rows, dtype=torch.int64, device=self.rt.device) if rows else None
+                return t, blk
+            self._ptable = {"all": build(0, self.total)}
+            if split:
+                self._ptable["lo"], self._ptable["hi"] = build(0, split), build(split, self.total)
+            self._ptable_split = split
+        return self._ptable
 
     def refresh_compute_copies(self, cast: bool = True):
         """P -> C (bf16 mode, unless Adam already wrote the shadow) and the transposed copies TR."""
         rt = self.rt
         if cast and rt.dt != L.MSC_F32:
             rt.call("msc_cast", self.P, self.C, self.total, rt.dt)
-        if self._ptable is None:
-            # descriptor table of every weight transpose: one launch per step instead of one per weight
-            rows, blk = [], 0
-            for r in self.refs.values():
-                if r.kind == "conv":
-                    d0, d1, d2 = r.shape[0], r.shape[1] * r.shape[2], r.shape[3]
-                elif r.kind == "linear":
-                    d0, d1, d2 = r.shape[0], 1, r.shape[1]
-                else:
-                    continue
-                rows.append([r.off, r.off, d0, d1, d2, blk])
-                blk += ((d2 + 31) // 32) * ((d0 + 31) // 32) * d1
-            self._ptable = torch.tensor(rows, dtype=torch.int64, device=rt.device)
-            self._pblocks = blk
-        rt.call("msc_permute3_cast_batched", self.P, self.TR, self._ptable, self._ptable.shape[0], self._pblocks, rt.dt)
+        t, blk = self._tables(self._ptable_split)["all"]
+        rt.call("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
 
-    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, overlap_from=None):
+        """Fused Adam (+ bf16 shadow) over the flat buffers, then the transposed compute copies.
+        overlap_from = element offset: parameters from there on (fusion transformer, codec, heads) are updated on the side
+        stream, where the update overlaps the camera/BEV trunks of the NEXT forward; MultimodalSC.forward joins the side
+        stream before the fusion reads them.  Not used while a hipGraph is being captured or in the instrumented pass."""
         rt = self.rt
         self.step_count += 1
         rt.call("msc_counter_add", self.step_dev, 1)          # the kernels read the step from device memory, so the
-        rt.call("msc_adam_step", self.P, self.G, self.M, self.V, None if rt.dt == L.MSC_F32 else self.C, self.total,
-                float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, self.step_dev,
-                float(grad_scale), rt.dt)                       # same launches replay correctly from a hipGraph
-        self.refresh_compute_copies(cast=False)
+        hp = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, self.step_dev,
+              float(grad_scale), rt.dt)                         # same launches replay correctly from a hipGraph
+        split = overlap_from if (overlap_from and rt.wgrad_on_side and rt.profile is None
+                                 and not torch.cuda.is_current_stream_capturing()) else None
+        if not split:
+            rt.call("msc_adam_step", self.P, self.G, self.M, self.V, None if rt.dt == L.MSC_F32 else self.C, self.total, *hp)
+            self.refresh_compute_copies(cast=False)
+            return
+        tabs = self._tables(split)
+        shadow = lambda a, b: None if rt.dt == L.MSC_F32 else self.C[a:b]
+        rt.call("msc_adam_step", self.P[:split], self.G[:split], self.M[:split], self.V[:split], shadow(0, split), split, *hp)
+        t, blk = tabs["lo"]
+        if t is not None:
+            rt.call("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
+        n_hi = self.total - split
+        rt.call_side("msc_adam_step", self.P[split:], self.G[split:], self.M[split:], self.V[split:], shadow(split, self.total), n_hi, *hp)
+        t, blk = tabs["hi"]
+        if t is not None:
+            rt.call_side("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)

@@ -76,6 +76,7 @@ class Trainer:
         self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
         self.split = model.params.refs["fusion.pos_embed"].off
         self.use_graph = os.environ.get("MSC_HIP_GRAPH", "0") == "1"
+        self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
         self._seen = 0
         self._graphs = None       # (gA, gB, gC) once captured
         self._static = None       # the batch whose tensors the graphs read
@@ -99,7 +100,9 @@ class Trainer:
         return out, terms
 
     def _adam(self):
-        self.model.params.adam_step(lr=self.lr, grad_scale=1.0 / self.world)
+        # the upper half of the parameters (transformer / codec / heads) is updated on the side stream: that update then
+        # overlaps the encoder trunks of the next forward instead of sitting on the critical chain (MSC_ADAM_OVERLAP=0: off)
+        self.model.params.adam_step(lr=self.lr, grad_scale=1.0 / self.world, overlap_from=self.split if self.adam_overlap else None)
 
     def _eager_step(self, batch):
         m, G = self.model, self.model.params.G
