@@ -245,3 +245,57 @@ def test_ppo_loop_collect_and_update(cuda):
     assert abs(buf.adv.mean().item()) < 1e-4 and abs(buf.adv.std().item() - 1) < 1e-3
     logs = ppo.update(buf, epochs=2, minibatch=64, generator=torch.Generator().manual_seed(3))
     assert len(logs) == 2 * (T * N // 64) and all(torch.isfinite(torch.tensor(l["loss"])) for l in logs)
+
+
+def test_hip_path_against_committed_golden_vectors(cuda):
+    """The HIP path (f32 mode) against tests/golden/oracle_c0_b8.npz — the frozen outputs of the oracle's C0 run — and the
+    small-kernel vectors (GAE, sampled actions, wire bytes, e4m3 grid) bit-exactly.  No oracle code runs on this side
+    except the seeded input generator."""
+    import os
+    import numpy as np
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from multimodal_sc_amd.wire import pack_symbols
+    from oracle import model as O
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    G = np.load(os.path.join(gdir, "oracle_c0_b8.npz"), allow_pickle=False)
+    om = O.build_oracle(O.named_config("C0"), seed=1)             # weights only (seeded init), no forward
+    batch = O.synthetic_batch(O.named_config("C0"), 8, seed=2)
+    m = MultimodalSC(named_config("C0"), dtype="f32", device="cuda:0")
+    m.load_oracle_state_dict(om.state_dict())
+    gb = _to(m.rt.device, batch)
+    out = m(gb["image"], None, None, gb["snr_db"], gb["noise"], gb["fading"])
+    terms = m.loss_and_grads(out, gb["image"], gb["ppo"])
+    torch.cuda.synchronize()
+    logits, _ = m.logits_value(out)
+    assert np.abs(logits.detach().cpu().numpy() - G["logits"]).max() < 1e-3
+    assert np.abs(out["symbols"].detach().float().cpu().numpy() - G["symbols"]).max() < 1e-3
+    met = m.metrics(terms)
+    assert abs(met["psnr"] - float(G["psnr"].mean())) < 1e-3
+    assert np.array_equal(m.select_action(out).cpu().numpy(), G["action"])
+    for k, want in zip(("mse", "policy", "value", "entropy", "loss"), G["terms"]):
+        assert abs(met[k] - want) < 1e-4 * max(1.0, abs(want)), (k, met[k], want)
+    gg = m.export_state_dict(grads=True)
+    norms = np.array([float(gg[str(k)].double().norm()) for k in G["grad_names"]])
+    assert np.allclose(norms, G["grad_norm"], rtol=3e-2, atol=1e-7)
+
+    S = np.load(os.path.join(gdir, "small_kernels.npz"), allow_pickle=False)
+    rt, dev = m.rt, m.rt.device
+    T, N = S["gae_rew"].shape
+    adv, ret = torch.empty(T, N, device=dev), torch.empty(T, N, device=dev)
+    rt.call("msc_gae", torch.from_numpy(S["gae_rew"]).to(dev), torch.from_numpy(S["gae_val"]).to(dev),
+            torch.from_numpy(S["gae_done"]).to(dev), adv, ret, T, N, 0.99, 0.95)
+    head = torch.zeros(64, 16)
+    head[:, :9] = torch.from_numpy(S["samp_logits"])
+    act = torch.empty(64, dtype=torch.int64, device=dev)
+    logp, val = torch.empty(64, device=dev), torch.empty(64, device=dev)
+    rt.call("msc_sample_actions", head.to(dev), act, logp, val, 64, 9, 16, 1234, None, 17, rt.dt)
+    q, s = pack_symbols(rt, torch.from_numpy(S["wire_x"]).to(dev))
+    n8 = S["e4m3_in"].shape[0] // 4 * 4
+    x8 = torch.from_numpy(S["e4m3_in"][:n8]).to(dev) * (448.0 / float(np.abs(S["e4m3_in"][:n8]).max()))   # amax == 448 -> scale 1
+    qb, dq, sc = torch.empty(n8, dtype=torch.uint8, device=dev), torch.empty(n8, device=dev), torch.empty(1, device=dev)
+    rt.call("msc_fp8_quantize", x8, qb, dq, sc, n8, rt.dt, rt.dt)
+    torch.cuda.synchronize()
+    assert np.array_equal(adv.cpu().numpy(), S["gae_adv"]) and np.array_equal(ret.cpu().numpy(), S["gae_ret"])
+    assert np.array_equal(act.cpu().numpy(), S["samp_action"]) and np.abs(logp.cpu().numpy() - S["samp_logp"]).max() < 1e-5
+    assert np.array_equal(q.cpu().numpy(), S["wire_q"]) and np.array_equal(s.cpu().numpy(), S["wire_scale"])
+    assert sc.item() == 1.0 and np.array_equal(dq.cpu().numpy(), O.e4m3_rne(x8.cpu()).numpy())

@@ -81,3 +81,49 @@ def test_wire_format_round_trip():
     assert np.all(np.abs(q).max(1)[[0, 1, 3]] == 127)            # the per-frame maximum always maps to +-127
     assert np.abs(W.unpack(q, s) - x).max() <= 0.5 * s.max() * (1 + 1e-6)
     assert math.isclose(float(s[0]), float(np.abs(x[0]).max() / np.float32(127.0)), rel_tol=1e-7)
+
+
+# ---- committed golden vectors (tests/golden/make_golden.py): the oracle must keep reproducing them
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), allow_pickle=False)
+
+
+def test_golden_small_kernels():
+    from oracle import philox, rl, wire
+    from oracle.model import e4m3_rne
+    G = _golden("small_kernels.npz")
+    r = philox.philox4x32_10(np.array([0, 1, 0xFFFFFFFF], np.uint32), np.array([0, 2, 0xFFFFFFFF], np.uint32),
+                             np.array([0, 3, 0xFFFFFFFF], np.uint32), np.array([0, 4, 0xFFFFFFFF], np.uint32), 0x0, 0x0)
+    assert np.array_equal(np.stack(r), G["philox"])
+    assert [hex(int(v)) for v in G["philox"][:, 0]] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]   # Random123 KAT
+    assert np.allclose(philox.philox_normal(4, 42, 1), G["normals"], atol=1e-6)
+    adv, ret = rl.gae(G["gae_rew"], G["gae_val"], G["gae_done"], 0.99, 0.95)
+    assert np.array_equal(adv, G["gae_adv"]) and np.array_equal(ret, G["gae_ret"])
+    act, logp = rl.sample_actions(G["samp_logits"], 1234, 17)
+    assert np.array_equal(act, G["samp_action"]) and np.allclose(logp, G["samp_logp"], atol=1e-6)
+    q, s = wire.pack(G["wire_x"])
+    assert np.array_equal(q, G["wire_q"]) and np.array_equal(s, G["wire_scale"])
+    assert np.array_equal(e4m3_rne(torch.from_numpy(G["e4m3_in"])).numpy(), G["e4m3_out"])
+
+
+def test_golden_oracle_c0():
+    """the C0 oracle run (configs[0], the reference's CPU-runnable case) against its committed outputs; tolerance covers
+    a different BLAS summation order on another host"""
+    from oracle import model as O
+    G = _golden("oracle_c0_b8.npz")
+    torch.set_num_threads(1)
+    cfg = O.named_config("C0")
+    om = O.build_oracle(cfg, seed=1)
+    b = O.synthetic_batch(cfg, 8, seed=2)
+    out = om(b["image"], b.get("points"), b.get("state"), b["snr_db"], b["noise"], b["fading"])
+    loss, terms = O.total_loss(out, b["image"], cfg, b["ppo"])
+    loss.backward()
+    assert np.allclose(out["logits"].detach().numpy(), G["logits"], atol=2e-4)
+    assert np.allclose(out["symbols"].detach().numpy(), G["symbols"], atol=2e-4)
+    assert np.allclose(O.psnr(out["recon"], b["image"]).detach().numpy(), G["psnr"], atol=1e-3)
+    assert np.array_equal(O.select_action(out["logits"]).numpy(), G["action"])
+    assert np.allclose([float(terms[k].detach()) for k in ("mse", "policy", "value", "entropy", "loss")], G["terms"], rtol=1e-4, atol=1e-5)
+    g = {k: p.grad for k, p in om.named_parameters()}
+    norms = np.array([float(g[k].double().norm()) for k in G["grad_names"]])
+    assert np.allclose(norms, G["grad_norm"], rtol=2e-2, atol=1e-7)     # training-mode BN over 8 samples: ill-conditioned
