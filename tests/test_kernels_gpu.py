@@ -667,3 +667,65 @@ def test_symbols_wire_format(rts, dtype):
     check("unpack", y, ref, tol(dtype))
     assert (ref - q(x, dtype)).abs().max() <= 0.5 * os_.max() * 1.001
     assert frame_bytes(k) == 260
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_invariants_c3_batch64(rts):
+    """BASELINE.json's full sizes (C3, 64 frames) are too large for the CPU oracle in a test, so the kernels are held to
+    size-independent properties there — all EXACT in bf16:
+      * attention with V == 1 returns 1 for every (token, channel) (softmax rows sum to one), its dV sums d(out);
+      * a linear layer is homogeneous: f(2x) == 2 f(x) bit for bit (no bias), and its weight gradient scales the same way;
+      * a 3x3 convolution with a centred delta kernel is the identity on the image-encoder layer-1 map;
+      * the power-normalised channel output has unit average power per frame at infinite SNR."""
+    from multimodal_sc_amd import functional as F
+    from multimodal_sc_amd import lib as L
+    rt = rts["bf16"]
+    dev_ = rt.device
+    B, T, h, hd = 64, 306, 8, 64
+    D = h * hd
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(B * T, 3 * D, generator=g)).to(torch.bfloat16)
+    qkv[:, 2 * D:] = 1.0
+    o, P = F.attention_fwd(rt, qkv.to(dev_), B, T, h, hd)
+    torch.cuda.synchronize()
+    assert torch.equal(o.float().cpu(), torch.ones(B * T, D))
+    # linear homogeneity at M = 64 * 306 rows
+    M, N, K = B * T, 1536, 512
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev_)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev_)
+    y1, y2 = rt.empty(M, N), rt.empty(M, N)
+    rt.call("msc_linear_fwd", x, w, None, None, y1, None, M, N, K, L.ACT_NONE, rt.dt)
+    rt.call("msc_linear_fwd", x * 2, w, None, None, y2, None, M, N, K, L.ACT_NONE, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(y2.float(), 2 * y1.float())
+    dw1, dw2 = torch.empty(N, K, device=dev_), torch.empty(N, K, device=dev_)
+    wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
+    ws = torch.empty(wsb // 4, device=dev_)
+    rt.call("msc_linear_wgrad", x, y1, dw1, ws, wsb, M, N, K, 0, rt.dt)
+    rt.call("msc_linear_wgrad", x * 2, y1, dw2, ws, wsb, M, N, K, 0, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, 2 * dw1)
+    # delta-kernel convolution == identity (64 x 56 x 56 x 64)
+    Bc, H, C = 64, 56, 64
+    xi = torch.randn(Bc, H, H, C, generator=g).to(torch.bfloat16).to(dev_)
+    wd = torch.zeros(C, 3, 3, C)
+    wd[torch.arange(C), 1, 1, torch.arange(C)] = 1.0
+    yo = rt.empty(Bc, H, H, C)
+    nrows = L.query("msc_conv2d_fwd_stat_rows", Bc * H * H, C)
+    part = torch.empty(nrows * 2 * C, device=dev_)
+    rt.call("msc_conv2d_fwd", xi, wd.to(torch.bfloat16).to(dev_), yo, part, Bc, H, H, C, C, 3, 3, 1, 1, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(yo, xi)
+    # the fused BN statistics of that launch are the column sums of the input
+    st = part.view(nrows, 2, C)
+    ref_sum = xi.float().sum((0, 1, 2))
+    assert (st[:, 0].sum(0) - ref_sum).abs().max() <= 2e-3 * xi.float().abs().sum((0, 1, 2)).max()
+    # channel: unit power at (practically) infinite SNR
+    k = 256
+    sym = torch.randn(B, k, generator=g).to(torch.bfloat16).to(dev_) * 3
+    yc, sc = rt.empty(B, k), torch.empty(B, device=dev_)
+    snr = torch.full((B,), 200.0, device=dev_)
+    rt.call("msc_channel_fwd", sym, None, None, snr, yc, sc, B, k, L.CH_AWGN, 7, None, rt.dt)
+    torch.cuda.synchronize()
+    pw = yc.float().pow(2).mean(1)
+    assert (pw - 1).abs().max() < 1e-2
