@@ -158,12 +158,14 @@ def test_bf16_end_to_end_parity_c3(cuda):
     assert all(a > b - 0.02 for a, b, _ in rows), [r for r in rows if r[0] <= r[1] - 0.02]
 
 
-def test_determinism_bitwise(cuda):
-    """run the same step twice: every output and every gradient must be bit-identical (no float atomics anywhere)."""
+@pytest.mark.parametrize("B", [2, 64])
+def test_determinism_bitwise(cuda, B):
+    """run the same step twice: every output and every gradient must be bit-identical (no float atomics anywhere) — also
+    at the full benchmark batch (64 frames), where split-K slices, three streams and every tile shape are in play."""
     from multimodal_sc_amd.model import MultimodalSC, named_config
     from oracle import model as O
     m = MultimodalSC(named_config("C3"), dtype="bf16", device="cuda:0", seed=3)
-    gb = _to(m.rt.device, O.synthetic_batch(O.named_config("C3"), 2, seed=5))
+    gb = _to(m.rt.device, O.synthetic_batch(O.named_config("C3"), B, seed=5))
     res = []
     for _ in range(2):
         out = m(gb["image"], gb["points"], gb["state"], gb["snr_db"], gb["noise"], gb["fading"])
