@@ -29,8 +29,10 @@ def normalize(x, eps=1e-8):
     return ((x - x.mean()) / (x.std(ddof=1) + eps)).astype(f32)
 
 
-def sample_actions(logits, seed, step):
-    """logits [B,A] float32 -> (action int64 [B], logp float32 [B]); u from Philox counter (row, step_lo, step_hi, 2)"""
+def sample_actions(logits, seed, step, return_margin=False):
+    """logits [B,A] float32 -> (action int64 [B], logp float32 [B]); u from Philox counter (row, step_lo, step_hi, 2).
+    return_margin: also the distance of u to the nearest CDF boundary (a sample closer than a few fp32 ulps to a boundary
+    may legitimately land on the neighbouring action when exp() differs in the last bit)."""
     lg = np.asarray(logits, dtype=f32)
     B, A = lg.shape
     z = np.zeros(B, np.uint32)
@@ -45,10 +47,14 @@ def sample_actions(logits, seed, step):
     c = np.zeros(B, f32)
     pick = np.full(B, A - 1, np.int64)
     found = np.zeros(B, bool)
+    margin = np.full(B, np.inf, f32)
     for a in range(A):
         c = c + e[:, a] / zsum
+        margin = np.minimum(margin, np.abs(c - u))
         hit = (c > u) & ~found
         pick[hit] = a
         found |= hit
     logp = (lg[np.arange(B), pick] - mx[:, 0]) - np.log(zsum, dtype=f32)
+    if return_margin:
+        return pick, logp.astype(f32), margin
     return pick, logp.astype(f32)

@@ -636,9 +636,13 @@ def test_sample_actions(rts, dtype):
     for step in (0, 7, (1 << 33) + 5):
         rt.call("msc_sample_actions", hd_, act, logp, val, B, A, ld, 1234, None, step, rt.dt)
         torch.cuda.synchronize()
-        oa, ol = R.sample_actions(seen[:, :A].numpy(), 1234, step)
-        assert np.array_equal(act.cpu().numpy(), oa), (act.cpu().numpy() != oa).sum()
-        assert np.abs(logp.cpu().numpy() - ol).max() < 1e-5
+        oa, ol, margin = R.sample_actions(seen[:, :A].numpy(), 1234, step, return_margin=True)
+        ga = act.cpu().numpy()
+        # bit-exact, except that a uniform within a few ulps of a CDF boundary may fall on the neighbouring action
+        # (expf on the GPU and np.exp can differ in the last bit); such rows are rare (~1e-6 of them) and must be adjacent
+        diff = ga != oa
+        assert diff.sum() <= 2 and np.all(margin[diff] < 1e-6) and np.all(np.abs(ga[diff] - oa[diff]) == 1), (diff.sum(), margin[diff])
+        assert np.abs(logp.cpu().numpy() - ol)[~diff].max() < 1e-5
         assert torch.equal(val.cpu(), seen[:, A])
     same = torch.zeros(B, ld)
     same[:, :A] = torch.tensor([2.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0])
