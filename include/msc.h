@@ -52,12 +52,19 @@ int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t re
  * bn_partial (may be NULL): fp32 [msc_conv2d_fwd_stat_rows(B*Ho*Wo, Cout)][2][Cout] per-row-block column
  * sums / sums of squares of the fp32 accumulators, reduced in fixed order by msc_bn_finalize (deterministic). */
 int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout);
+/* ws / ws_bytes (may be NULL / 0): fp32 scratch of msc_conv2d_splitk_workspace_bytes(rows_out, cols_out, k_len, dtype)
+ * bytes.  Launches that cannot fill the chip (deep layers: few output rows, long K) then run as split-K over 128x128
+ * tiles + a fixed-order finish kernel that also writes bn_partial; without the workspace the un-split kernel runs.
+ * forward: rows_out = B*Ho*Wo, cols_out = Cout, k_len = KH*KW*Cin; dgrad: rows_out = B*H*W, cols_out = Cin,
+ * k_len = KH*KW*Cout (stride-1 dgrad only). */
+int64_t msc_conv2d_splitk_workspace_bytes(int64_t rows_out, int cols_out, int64_t k_len, int dtype);
 int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_partial, int B, int H, int W,
-                   int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream);
+                   int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype,
+                   void* stream);
 /* dx:[B,H,W,Cin] = conv-transpose of dy:[B,Ho,Wo,Cout] with wt:[Cin,KH,KW,Cout] (msc_permute3_cast)
  * + res (optional T [B,H,W,Cin]: the gradient arriving over a residual/identity branch). */
 int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, void* dx, int B, int H, int W, int Cin,
-                     int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream);
+                     int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream);
 /* dw (fp32, OHWI) = sum over pixels dy^T x.  accumulate!=0 adds to dw.  ws: see msc_wgrad_workspace_bytes. */
 int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,
                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,

@@ -347,6 +347,14 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
     ks.kh = kh0;
     ks.kw = s_kw0;
     ks.kbase = (kh0 * p.cKW + s_kw0) << p.cLogC;
+    if (p.nsplit > 1) {   // split-K dgrad (the host only splits the plain (b,h,w) order): this slice starts mid-schedule
+      const int e = kt_begin * KT, tap = e >> p.cLogC;
+      ks.co0 = e & (p.cC - 1);
+      ks.kh = tap / p.cKW;
+      ks.kw = tap - ks.kh * p.cKW;
+      ks.kbase = e;
+      nk = kt_end - kt_begin;
+    }
   }
   auto advance = [&]() {
     if constexpr (AMODE == OPM_CONV_DGRAD) {
@@ -709,6 +717,69 @@ __global__ __launch_bounds__(64 * RY) void splitk_reduce_kernel(const float* __r
   }
 }
 
+// Finish of a split-K conv forward / dgrad: y[m][n] = T( sum_s slab[s][m][n] (+ res[m][n]) ), optionally with the BatchNorm
+// partial statistics (sum, sum of squares per channel over each block of RB rows) the un-split epilogue would have written.
+// Block = 64 columns x RB rows: thread (c4 = 4 columns, rl = one of 16 row lanes); fixed summation order everywhere.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int ns, long M, int N, T* __restrict__ y,
+                                                            const T* __restrict__ res, float* __restrict__ stats, int RB) {
+  __shared__ float red[2][16][64];
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + c4 * 4;
+  const long r0 = (long)blockIdx.y * RB;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    for (int r = rl; r < RB; r += 16) {
+      const long m = r0 + r;
+      if (m >= M) break;
+      const long e = m * N + n;
+      float4 a = *reinterpret_cast<const float4*>(slab + e);
+      for (int k = 1; k < ns; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(slab + (long)k * M * N + e);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      float v[4] = {a.x, a.y, a.z, a.w};
+      s1[0] += v[0]; s1[1] += v[1]; s1[2] += v[2]; s1[3] += v[3];
+      s2[0] += v[0] * v[0]; s2[1] += v[1] * v[1]; s2[2] += v[2] * v[2]; s2[3] += v[3] * v[3];
+      if (res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += msc_traits<T>::ld(res + e + j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) msc_traits<T>::st(y + e + j, v[j]);
+    }
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][rl][c4 * 4 + j] = s1[j]; red[1][rl][c4 * 4 + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < 16; ++r) { a += red[0][r][threadIdx.x]; b += red[1][r][threadIdx.x]; }
+    float* st = stats + (long)blockIdx.y * 2 * N;
+    st[blockIdx.x * 64 + threadIdx.x] = a;
+    st[N + blockIdx.x * 64 + threadIdx.x] = b;
+  }
+}
+
+// Split-K for chip-underfilling conv forward / stride-1 dgrad launches (the deep ResNet layers: 64 frames x 7x7 or 14x14
+// pixels give 100-200 tiles of 128x128 for 256 CUs, and 64-wide tiles run 4 MFMAs per barrier): 128x128 tiles over ns K
+// slices + the finish kernel above.  Returns 1 when the launch fills the chip or K is too short to split.
+static int plan_conv_split(long M, long N, long nk) {
+  static const int on = getenv("MSC_CONV_SPLITK") ? atoi(getenv("MSC_CONV_SPLITK")) : 1;   // A/B knob
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+  if (!on || tiles >= 200 || nk < 32 || N % 4) return 1;
+  long ns = (400 + tiles - 1) / tiles;
+  if (ns > 8) ns = 8;
+  while (ns > 1 && nk / ns < 16) --ns;
+  return (int)ns;
+}
+
+extern "C" int64_t msc_conv2d_splitk_workspace_bytes(int64_t rows, int cout, int64_t k_len, int dtype) {
+  const int ns = plan_conv_split(rows, cout, cdiv(k_len, dtype == MSC_F32 ? 16 : 32));
+  return ns > 1 ? (int64_t)ns * rows * cout * 4 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile choice: narrow operands get 64-wide tiles; launches that would leave most of the 256 CUs idle trade MFMA work
 // per LDS byte for more workgroups
@@ -841,8 +912,32 @@ static int set_conv_geom(GemmParams& p, int B, int H, int W, int C, int Ho, int 
   return (p.cLogC >= 0 && p.cLogS >= 0) ? MSC_OK : MSC_ERR_BAD_ARG;
 }
 
+// shared tail of msc_conv2d_fwd / msc_conv2d_dgrad: split-K launch + finish when it pays and the workspace allows
+template <int AMODE>
+static int launch_conv_maybe_split(GemmParams& p, void* out, const void* res, float* stats, float* ws, int64_t ws_bytes, int dtype,
+                                   hipStream_t st) {
+  const int nk = cdiv(p.K, kt_of(dtype));
+  const int ns0 = (AMODE == OPM_CONV_DGRAD && p.cls) ? 1 : plan_conv_split(p.M, p.N, nk);
+  if (ns0 <= 1 || !ws || ws_bytes < (int64_t)ns0 * p.M * p.N * 4) return launch_gemm_dt<AMODE, OPM_DENSE_K>(p, 1, dtype, st);
+  const int tps = cdiv(nk, ns0), ns = cdiv(nk, tps);
+  int bm0, bn0;
+  choose_tile(p.M, p.N, 1, bm0, bn0);          // row granularity of the BatchNorm partials the caller sized its buffer for
+  p.nsplit = ns;
+  p.tiles_per_split = tps;
+  p.C = ws; p.ldc = p.N; p.out_f32 = 1;
+  p.stats = nullptr; p.res = nullptr;
+  int rc = launch_gemm_dt<AMODE, OPM_DENSE_K>(p, 1, dtype, st);
+  if (rc != MSC_OK) return rc;
+  const dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, bm0));
+  if (dtype == MSC_F32)
+    hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (float*)out, (const float*)res, stats, bm0);
+  else
+    hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (bf16_t*)out, (const bf16_t*)res, stats, bm0);
+  return msc_launch_status();
+}
+
 extern "C" int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_partial, int B, int H, int W, int Cin,
-                              int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+                              int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream) {
   MSC_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(Cin >= vec_of(dtype) && ilog2_exact(Cin) >= 0 && Cout > 0);
@@ -854,11 +949,11 @@ extern "C" int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_p
   p.M = B * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin;
   p.ldb = p.K; p.ldc = Cout;
   if (set_conv_geom(p, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad) != MSC_OK) return MSC_ERR_BAD_ARG;
-  return launch_gemm_dt<OPM_CONV_FWD, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
+  return launch_conv_maybe_split<OPM_CONV_FWD>(p, y, nullptr, bn_partial, ws, ws_bytes, dtype, (hipStream_t)stream);
 }
 
 extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, void* dx, int B, int H, int W, int Cin,
-                                int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+                                int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && wt && dx && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(Cout >= vec_of(dtype) && ilog2_exact(Cout) >= 0 && Cin > 0 && ilog2_exact(stride) >= 0);
@@ -877,7 +972,7 @@ extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res,
     p.cW2 = W / stride;
     p.cMc = B * p.cH2 * p.cW2;
   }
-  return launch_gemm_dt<OPM_CONV_DGRAD, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
+  return launch_conv_maybe_split<OPM_CONV_DGRAD>(p, dx, res, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream);
 }
 
 extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,

@@ -33,7 +33,9 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
     nblk = L.query("msc_conv2d_fwd_stat_rows", M, Cout)
     y_raw = rt.empty(B, Ho, Wo, Cout)
     partial = rt.workspace("bn_partial", nblk * 2 * Cout * 4)
-    rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.dt)
+    wsb = L.query("msc_conv2d_splitk_workspace_bytes", M, Cout, KH * KW * Cin, rt.dt)     # > 0: chip-underfilling launch -> split-K
+    ws = rt.workspace("conv_splitk", wsb) if wsb else None
+    rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsb, rt.dt)
     stats = rt.f32(4, Cout)                      # mean, rstd (kept for backward), scale, shift (folded affine)
     mean, rstd = stats[0], stats[1]
     rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, gamma.p, beta.p, mean, rstd, stats[2], stats[3])
@@ -72,7 +74,9 @@ def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, mean, rstd, conv: ParamRef, gamma:
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
-        rt.call("msc_conv2d_dgrad", d_raw, conv.t, dx_res, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, rt.dt)
+        wsd = L.query("msc_conv2d_splitk_workspace_bytes", B * H * W, Cin, KH * KW * Cout, rt.dt) if stride == 1 else 0
+        ws = rt.workspace("conv_splitk", wsd) if wsd else None
+        rt.call("msc_conv2d_dgrad", d_raw, conv.t, dx_res, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsd, rt.dt)
     return dx, dres
 
 

@@ -47,7 +47,7 @@ def test_pure_host_entry_points(built_lib):
     assert L.query("msc_wgrad_workspace_bytes", 64, 576, 200704) > 0
     # argument validation happens before any HIP call: bad sizes are refused without touching a device
     assert L.lib.msc_linear_fwd(None, None, None, None, None, None, 1, 1, 8, 0, 0, None) == -1
-    assert L.lib.msc_conv2d_fwd(1, 1, 1, None, 1, 8, 8, 3, 8, 3, 3, 1, 1, 1, None) == -1      # Cin=3 not a power of two >= 8
+    assert L.lib.msc_conv2d_fwd(1, 1, 1, None, 1, 8, 8, 3, 8, 3, 3, 1, 1, None, 0, 1, None) == -1      # Cin=3 not a power of two >= 8
 
 
 def test_product_fails_loudly_without_extension(tmp_path):

@@ -717,7 +717,7 @@ def test_full_size_invariants_c3_batch64(rts):
     yo = rt.empty(Bc, H, H, C)
     nrows = L.query("msc_conv2d_fwd_stat_rows", Bc * H * H, C)
     part = torch.empty(nrows * 2 * C, device=dev_)
-    rt.call("msc_conv2d_fwd", xi, wd.to(torch.bfloat16).to(dev_), yo, part, Bc, H, H, C, C, 3, 3, 1, 1, rt.dt)
+    rt.call("msc_conv2d_fwd", xi, wd.to(torch.bfloat16).to(dev_), yo, part, Bc, H, H, C, C, 3, 3, 1, 1, None, 0, rt.dt)
     torch.cuda.synchronize()
     assert torch.equal(yo, xi)
     # the fused BN statistics of that launch are the column sums of the input

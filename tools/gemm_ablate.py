@@ -67,7 +67,7 @@ def child(n):
         Ho = (H + 2 * p - Kk) // s + 1
         x, w, y = rnd(B, H, H, Cin), rnd(Cout, Kk, Kk, Cin), rnd(B, Ho, Ho, Cout)
         part = torch.empty((B * Ho * Ho + 63) // 64 * 2 * Cout, device=dev)
-        t = timeit(lambda: rt.call("msc_conv2d_fwd", x, w, y, part, B, H, H, Cin, Cout, Kk, Kk, s, p, rt.dt))
+        t = timeit(lambda: rt.call("msc_conv2d_fwd", x, w, y, part, B, H, H, Cin, Cout, Kk, Kk, s, p, None, 0, rt.dt))
         out.append(("conv_fwd " + name, t, 2.0 * B * Ho * Ho * Cout * Kk * Kk * Cin))
         dw = torch.empty(Cout, Kk, Kk, Cin, device=dev)
         wsb = L.query("msc_wgrad_workspace_bytes", Cout, Kk * Kk * Cin, B * Ho * Ho)
@@ -75,7 +75,7 @@ def child(n):
         t = timeit(lambda: rt.call("msc_conv2d_wgrad", x, y, dw, ws, wsb, B, H, H, Cin, Cout, Kk, Kk, s, p, 0, rt.dt))
         out.append(("conv_wgrad " + name, t, 2.0 * B * Ho * Ho * Cout * Kk * Kk * Cin))
         wt, dx = rnd(Kk, Kk, Cin, Cout), rnd(B, H, H, Cin)
-        t = timeit(lambda: rt.call("msc_conv2d_dgrad", y, wt, None, dx, B, H, H, Cin, Cout, Kk, Kk, s, p, rt.dt))
+        t = timeit(lambda: rt.call("msc_conv2d_dgrad", y, wt, None, dx, B, H, H, Cin, Cout, Kk, Kk, s, p, None, 0, rt.dt))
         out.append(("conv_dgrad " + name, t, 2.0 * B * Ho * Ho * Cout * Kk * Kk * Cin))
     for name, t, fl in out:
         print(f"RES|{n}|{name}|{t:.1f}|{fl / t / 1e6:.0f}", flush=True)

@@ -57,11 +57,15 @@ for name, H, Cin, Cout, K, s, p in convs:
     part = torch.empty((B * Ho * Ho + 63) // 64 * 2 * Cout, device=dev)
     cin_real = 3 if Cin == 8 else Cin
     fl = 2.0 * B * Ho * Ho * Cout * K * K * cin_real
-    t = timeit(lambda: rt.call("msc_conv2d_fwd", x, w, y, part, B, H, H, Cin, Cout, K, K, s, p, rt.dt))
+    wsb = L.query("msc_conv2d_splitk_workspace_bytes", B * Ho * Ho, Cout, K * K * Cin, rt.dt)
+    wsf = torch.empty(max(wsb // 4, 1), device=dev) if wsb else None
+    t = timeit(lambda: rt.call("msc_conv2d_fwd", x, w, y, part, B, H, H, Cin, Cout, K, K, s, p, wsf, wsb, rt.dt))
     rows.append((f"conv_fwd {name} H{H} {Cin}->{Cout}", t, fl))
     if Cin != 8:
         wt, dx = rnd(Cin, K, K, Cout), rnd(B, H, H, Cin)
-        t = timeit(lambda: rt.call("msc_conv2d_dgrad", y, wt, None, dx, B, H, H, Cin, Cout, K, K, s, p, rt.dt))
+        wsd = L.query("msc_conv2d_splitk_workspace_bytes", B * H * H, Cin, K * K * Cout, rt.dt) if s == 1 else 0
+        wsg = torch.empty(max(wsd // 4, 1), device=dev) if wsd else None
+        t = timeit(lambda: rt.call("msc_conv2d_dgrad", y, wt, None, dx, B, H, H, Cin, Cout, K, K, s, p, wsg, wsd, rt.dt))
         rows.append((f"conv_dgrad {name}", t, fl))
     dw = torch.empty(Cout, K, K, Cin, device=dev)
     wsb = L.query("msc_wgrad_workspace_bytes", Cout, K * K * Cin, B * Ho * Ho)
