@@ -769,7 +769,7 @@ static int plan_conv_split(long M, long N, long nk) {
   static const int on = getenv("MSC_CONV_SPLITK") ? atoi(getenv("MSC_CONV_SPLITK")) : 1;   // A/B knob
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
   if (!on || tiles >= 200 || nk < 32 || N % 4) return 1;
-  long ns = (400 + tiles - 1) / tiles;
+  long ns = (400 + tiles / 2) / tiles;     // ~400 workgroups (measured: layer3 best at 2 slices, layer4 at 4)
   if (ns > 8) ns = 8;
   while (ns > 1 && nk / ns < 16) --ns;
   return (int)ns;
