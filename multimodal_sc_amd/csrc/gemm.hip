@@ -795,8 +795,9 @@ static void choose_tile(long M, long N, long zs, int& bm, int& bn, bool allow256
   // better with the side-stream weight gradients for everything smaller (step 9.07 -> 8.99 ms), although the 256-row
   // tile wins some of those shapes when they run alone.
   if (allow256 && bn == 128 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 128) * zs >= 1000) { bm = 256; return; }
-  if (bn == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bn = 64;
-  if (bm == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 320) bm = 64;
+  // (threshold measured inside the step: 200 tiles; 320+ shrinks tiles that were better left at 128)
+  if (bn == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 200) bn = 64;
+  if (bm == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 200) bm = 64;
 }
 
 // rows of the BatchNorm partial-statistics buffer msc_conv2d_fwd writes for an output of `rows` pixels x `cout`
