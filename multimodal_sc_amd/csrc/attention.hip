@@ -427,7 +427,9 @@ extern "C" int msc_attention_bwd(const void* qkv, const void* o, const void* dou
   hipStream_t st = (hipStream_t)stream;
   const float c = scale * 1.4426950408889634f;
   static int nwb_env = getenv("MSC_ATT_BWD_WAVES") ? atoi(getenv("MSC_ATT_BWD_WAVES")) : 0;   // tuning knob (A/B runs)
-  const int nwb = nwb_env > 0 ? (nwb_env > 8 ? 8 : nwb_env) : nw;   // <= 8 waves: the kernels need ~190 VGPRs (two waves per SIMD)
+  // <= 8 waves: the kernels need ~190-256 VGPRs (two waves per SIMD); 8 measured best inside the step (5: -0.5 %)
+  const int nt = Tpad / 32;
+  const int nwb = nwb_env > 0 ? (nwb_env > 8 ? 8 : nwb_env) : (nt < 8 ? nt : 8);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(64 * nwb), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                      delta, (bf16_t*)dqkv, T, Tpad, H, c, scale);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(64 * nwb), lds, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,

@@ -10,7 +10,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "msc.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libmsc_hip.so")
+# MSC_LIB_PATH: development knob (A/B runs of alternative builds of the SAME library); there is still no fallback path
+LIB_PATH = os.environ.get("MSC_LIB_PATH") or os.path.join(_HERE, "csrc", "libmsc_hip.so")
 
 MSC_F32, MSC_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
