@@ -343,8 +343,18 @@ class MultimodalSC:
         return img
 
     # ------------------------------------------------------------------ loss + backward
-    def backward_lower(self):
-        """phase 2 of the backward: encoders (ResNet-18, BEV, state) from the gradients phase 1 left at the boundary"""
+    def mid_offset(self):
+        """element offset in the flat buffers of the first parameter whose gradient is final after the first two phases of
+        backward_lower (top of the camera trunk, BEV branch, state encoder), or None when the step has no such split"""
+        if not (self.cfg.use_lidar and self.rt.branch_streams and 1 <= self._img_cut <= 3):
+            return None
+        return self.params.refs[f"image_encoder.layer{self._img_cut + 1}.0.conv1.weight"].off
+
+    def backward_lower(self, on_mid=None):
+        """phase 2 of the backward: encoders (ResNet-18, BEV, state) from the gradients phase 1 left at the boundary.
+        on_mid: callback fired once everything whose parameters lie at or above mid_offset() has been ENQUEUED (top of the
+        trunk + state encoder on the main stream, BEV branch on its stream, their weight gradients on the side stream) —
+        the trainer starts the all-reduce of that slice there, under the rest of the trunk's backward."""
         rt = self.rt
         outs, grads = self._enc_out, [t.grad for t in self._enc_in]
         if self._bev_slot is not None and rt._branch is not None:
@@ -356,11 +366,16 @@ class MultimodalSC:
             #     is made current for that call: the engine ends a backward by making the CALLER's stream wait for every
             #     stream it used, which would stall the main stream for the whole BEV backward.
             #  3. the rest of the camera trunk and the state encoder.
+            mid_ready = False
             if self._img_cut_in is not None:
-                torch.autograd.backward([outs[0]], [grads[0]])
-                outs, grads = [self._img_cut_out] + outs[1:], [self._img_cut_in.grad] + grads[1:]
+                # (the state encoder — two tiny layers whose parameters sit above mid_offset() — rides along)
+                rest = [j for j in range(len(outs)) if j not in (0, self._bev_slot)]
+                torch.autograd.backward([outs[0]] + [outs[j] for j in rest], [grads[0]] + [grads[j] for j in rest])
+                outs = [self._img_cut_out, outs[self._bev_slot]]
+                grads = [self._img_cut_in.grad, grads[self._bev_slot]]
                 self._img_cut_out = self._img_cut_in = None
-            i = self._bev_slot
+                mid_ready = True
+            i = 1 if mid_ready else self._bev_slot
             main, s2 = torch.cuda.current_stream(rt.device), rt._branch
             s2.wait_stream(main)
             if not torch.cuda.is_current_stream_capturing():
@@ -368,6 +383,8 @@ class MultimodalSC:
             with torch.cuda.stream(s2):
                 torch.autograd.backward([outs[i]], [grads[i]])
             outs, grads = outs[:i] + outs[i + 1:], grads[:i] + grads[i + 1:]
+            if mid_ready and on_mid is not None:
+                on_mid()
         torch.autograd.backward(outs, grads)
         self._enc_out = self._enc_in = None
         rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them

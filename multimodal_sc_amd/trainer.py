@@ -22,7 +22,9 @@ exchange step of the path is the gradient sum over the flat fp32 gradient buffer
 "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests) in two large pieces:
   upper  G[fusion.pos_embed:]  (transformer, semantic codec, heads: ~56 MB) — final after backward phase 1; its
          all-reduce runs under the whole encoder backward (phase 2);
-  lower  G[:fusion.pos_embed]  (image / BEV / state encoders: ~52 MB) — reduced after phase 2.
+  mid    G[layer4:fusion.pos_embed]  (top of the camera trunk, BEV branch, state encoder: ~40 MB) — final once the first
+         two phases of the encoder backward are done; reduced under the rest of the trunk's backward;
+  rest   G[:layer4]  (stem .. layer3: ~11 MB) — the only piece left exposed after the backward.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): few, large messages let RCCL drive all links; small buckets
 would be latency-bound per link.  MSC_DP_OVERLAP=0 falls back to one non-overlapped bucketed all-reduce.
 """
@@ -76,6 +78,8 @@ class Trainer:
         self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
         self.split = model.params.refs["fusion.pos_embed"].off
         self.use_graph = os.environ.get("MSC_HIP_GRAPH", "0") == "1"
+        self.dp_pieces = int(os.environ.get("MSC_DP_PIECES", "3"))    # 2: upper + encoders; 3: upper + mid + rest of the trunk
+        self._mid_stream = None
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
         self._seen = 0
         self._graphs = None       # (gA, gB, gC) once captured
@@ -99,6 +103,23 @@ class Trainer:
         terms = m.loss_and_grads(out, batch["image"], batch.get("ppo") if self.use_ppo else None)
         return out, terms
 
+    def _allreduce_mid(self, mid):
+        """all-reduce of G[mid:split] (top of the camera trunk, BEV branch, state encoder: ~40 of the 52 MB of encoder
+        gradients) started while the rest of the trunk's backward is still being enqueued.  Its producers run on three
+        streams (main, BEV branch, side); a helper stream waits for all of them and is current when the collective is
+        issued, so the main stream is not held up."""
+        m, rt = self.model, self.model.rt
+        if self._mid_stream is None:
+            self._mid_stream = torch.cuda.Stream(rt.device)
+        s3, main = self._mid_stream, torch.cuda.current_stream(rt.device)
+        s3.wait_stream(main)
+        if rt._branch is not None:
+            s3.wait_stream(rt._branch)
+        if rt.side is not None:
+            s3.wait_stream(rt.side)
+        with torch.cuda.stream(s3):
+            return dist.all_reduce(m.params.G[mid:self.split], op=dist.ReduceOp.SUM, async_op=True)
+
     def _adam(self):
         # the upper half of the parameters (transformer / codec / heads) is updated on the side stream: that update then
         # overlaps the encoder trunks of the next forward instead of sitting on the critical chain (MSC_ADAM_OVERLAP=0: off)
@@ -111,8 +132,10 @@ class Trainer:
         elif self.overlap:
             _, terms = self._forward_upper(batch)
             works = [dist.all_reduce(G[self.split:], op=dist.ReduceOp.SUM, async_op=True)]
-            m.backward_lower()
-            works.append(dist.all_reduce(G[: self.split], op=dist.ReduceOp.SUM, async_op=True))
+            mid = m.mid_offset() if self.dp_pieces >= 3 else None
+            m.backward_lower(on_mid=(lambda: works.append(self._allreduce_mid(mid))) if mid is not None else None)
+            lo_end = mid if (mid is not None and len(works) == 2) else self.split
+            works.append(dist.all_reduce(G[:lo_end], op=dist.ReduceOp.SUM, async_op=True))
             for w in works:
                 w.wait()
         else:
