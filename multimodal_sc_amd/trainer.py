@@ -79,7 +79,6 @@ class Trainer:
         self.split = model.params.refs["fusion.pos_embed"].off
         self.use_graph = os.environ.get("MSC_HIP_GRAPH", "0") == "1"
         self.dp_pieces = int(os.environ.get("MSC_DP_PIECES", "3"))    # 2: upper + encoders; 3: upper + mid + rest of the trunk
-        self._mid_stream = None
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
         self._seen = 0
         self._graphs = None       # (gA, gB, gC) once captured
@@ -104,20 +103,18 @@ class Trainer:
         return out, terms
 
     def _allreduce_mid(self, mid):
-        """all-reduce of G[mid:split] (top of the camera trunk, BEV branch, state encoder: ~40 of the 52 MB of encoder
+        """all-reduce of G[mid:split] (top of the camera trunk, BEV branch, state encoder: ~41 of the 52 MB of encoder
         gradients) started while the rest of the trunk's backward is still being enqueued.  Its producers run on three
-        streams (main, BEV branch, side); a helper stream waits for all of them and is current when the collective is
-        issued, so the main stream is not held up."""
+        streams (main, BEV branch, side).  The collective is issued with the BEV-branch stream current — that stream has
+        nothing left to do once its backward is enqueued — after making it wait for the other two, so the main stream is
+        not held up and NO further stream is created: with five or more streams active the HIP runtime on this stack
+        serialises badly (measured: a third side stream took the step from 9.1 to 16 ms)."""
         m, rt = self.model, self.model.rt
-        if self._mid_stream is None:
-            self._mid_stream = torch.cuda.Stream(rt.device)
-        s3, main = self._mid_stream, torch.cuda.current_stream(rt.device)
-        s3.wait_stream(main)
-        if rt._branch is not None:
-            s3.wait_stream(rt._branch)
+        s2, main = rt._branch, torch.cuda.current_stream(rt.device)
+        s2.wait_stream(main)
         if rt.side is not None:
-            s3.wait_stream(rt.side)
-        with torch.cuda.stream(s3):
+            s2.wait_stream(rt.side)
+        with torch.cuda.stream(s2):
             return dist.all_reduce(m.params.G[mid:self.split], op=dist.ReduceOp.SUM, async_op=True)
 
     def _adam(self):
