@@ -25,21 +25,34 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
+PMC_HBM_SUMMARY = "profiles/r2_pmc_hbm_bench_c3.csv"
+
+
+def gemm_source_sha():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "multimodal_sc_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+
+
 def pmc_hbm_bytes_per_gemm_launch():
     """HBM bytes per launch of the contraction kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, separate passes over this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM;
-    tools/pmc_hbm_summary.py).  Counters cannot be read from inside the timed process, so the figure comes from the profile
-    file; None when it is absent."""
+    tools/pmc_hbm_summary.py).  Hardware counters cannot be read from inside the timed process, so the figure comes from the
+    profile file — and ONLY while that file was taken on the kernel source that is being benchmarked: the summary's
+    sidecar (<csv>.meta.json, written by tools/pmc_hbm_summary.py) records the sha256 of csrc/gemm.hip at profiling time;
+    if it is missing or differs from the current source the figure is stale and traffic is reported as null."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_bench_c3.csv")
-    if not os.path.exists(path):
-        return None, None
+    path = os.path.join(ROOT, PMC_HBM_SUMMARY)
+    meta = path + ".meta.json"
+    if not (os.path.exists(path) and os.path.exists(meta)):
+        return None, "no PMC summary for this build"
+    if json.load(open(meta)).get("gemm_hip_sha256_16") != gemm_source_sha():
+        return None, f"{PMC_HBM_SUMMARY} is stale (csrc/gemm.hip changed since the PMC pass)"
     b = n = 0.0
     for r in csv.DictReader(open(path)):
         if "gemm_kernel<unsigned short" in r["kernel"]:
             b += float(r["fetch_bytes_corrected_x2"]) + float(r["write_bytes"])
             n += int(r["calls"])
-    return (b / n if n else None), "profiles/r1_pmc_hbm_bench_c3.csv"
+    return (b / n if n else None), PMC_HBM_SUMMARY + " (committed profile of this source)"
 
 
 def gemm_flops(name, s):
@@ -88,31 +101,72 @@ def gemm_bytes(name, s):
     return None
 
 
-def cpu_baseline(cfg_name, seconds_budget=20.0):
-    """oracle fwd+bwd (fp32, all host threads) on a bounded sample of the same workload -> frames/s"""
+def cpu_baseline(cfg_name, seconds_budget=25.0):
+    """oracle fwd+bwd (fp32, all host threads) on a bounded sample of the same workload -> frames/s.
+    The batch is the largest of 64/32 whose measured step fits the time budget (a small batch cannot feed a many-core host,
+    which would understate the baseline): one probing step at 32 frames decides whether 64 fits; the reported rate is
+    the best batch's steady steps."""
     import torch
     from oracle import model as O
     cfg = O.named_config(cfg_name)
-    B = 4
     m = O.build_oracle(cfg, seed=0)
-    batch = O.synthetic_batch(cfg, B, seed=0)
 
-    def step():
-        for p in m.parameters():
-            p.grad = None
-        out = m(batch["image"], batch.get("points"), batch.get("state"), batch["snr_db"], batch["noise"], batch["fading"])
-        loss, _ = O.total_loss(out, batch["image"], cfg, batch["ppo"])
-        loss.backward()
+    def make_step(B):
+        batch = O.synthetic_batch(cfg, B, seed=0)
 
-    step()  # warm-up
+        def step():
+            for p in m.parameters():
+                p.grad = None
+            out = m(batch["image"], batch.get("points"), batch.get("state"), batch["snr_db"], batch["noise"], batch["fading"])
+            loss, _ = O.total_loss(out, batch["image"], cfg, batch["ppo"])
+            loss.backward()
+        return step
+
+    t_start = time.time()
+    B = 32
+    step = make_step(B)
+    step()                                   # warm-up (allocator, thread pool)
     t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 6):
+    step()
+    t32 = time.time() - t0
+    best = (B / t32, B, 1)
+    if 2 * t32 * 3 < seconds_budget - (time.time() - t_start):      # warm-up + 2 timed steps at 64 frames fit
+        B = 64
+        step = make_step(B)
+        step()
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t_start < seconds_budget and n < 4):
         step()
         n += 1
-    dt = time.time() - t0
-    return {"value": B * n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/model.py fwd+bwd, config {cfg_name}, batch {B} x {n} steps, fp32, no optimizer step"}
+    rate = B * n / (time.time() - t0)
+    if rate > best[0]:
+        best = (rate, B, n)
+    return {"value": best[0], "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/model.py fwd+bwd, config {cfg_name}, batch {best[1]} x {best[2]} timed steps, fp32, "
+                      f"{torch.get_num_threads()} threads of {os.cpu_count()} host cpus, no optimizer step"}
+
+
+def allreduce_probe(model, trainer, dist, torch, reps=5):
+    """N>1, outside the timed region: each piece of the gradient exchange alone (barrier, `reps` all-reduces, max over
+    ranks) -> ms and algorithmic GB/s per rank, so a scaling run explains itself."""
+    G = model.params.G
+    ex = trainer.exchange
+    pieces = [(n, lo, hi) for n, lo, hi in ex.log] if ex is not None and ex.log else [("flat", 0, G.numel())]
+    out = {}
+    for name, lo, hi in pieces:
+        buf = torch.zeros(hi - lo, dtype=G.dtype, device=G.device)
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=G.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item()) * 1e3
+        out[name] = {"mbytes": (hi - lo) * 4 / 1e6, "ms": ms, "GB_per_s": (hi - lo) * 4 / 1e9 / (ms * 1e-3)}
+    return out
 
 
 def main():
@@ -130,8 +184,8 @@ def main():
     import torch
     import torch.distributed as dist
     from multimodal_sc_amd.model import MultimodalSC, named_config
-    from multimodal_sc_amd.trainer import Trainer
-    from oracle import model as O   # synthetic input generator only; never on the measured path
+    from multimodal_sc_amd.synthetic import synthetic_batch     # seeded input generator of the product package: the GPU
+    from multimodal_sc_amd.trainer import Trainer               # leg imports nothing from oracle/
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +208,7 @@ def main():
     model = MultimodalSC(cfg, dtype=args.dtype, device=dev, seed=0)
     trainer = Trainer(model, lr=1e-4, use_ppo=True)
     B = args.batch
-    cpu_batch = O.synthetic_batch(O.named_config(args.config), B, seed=1000 + rank)
+    cpu_batch = synthetic_batch(cfg, B, seed=1000 + rank)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in cpu_batch.items() if k != "ppo"}
     batch["ppo"] = {k: v.to(dev) for k, v in cpu_batch["ppo"].items()}
     batch["noise"] = None      # throughput mode: in-kernel Philox noise
@@ -197,13 +251,24 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         result["dp_params_in_sync"] = bool((lo == hi).item())
+        result["rccl_ranks"] = dist.get_world_size()
+        result["dp_backend"] = backend
+        result["dp_schedule"] = [list(x) for x in trainer.exchange.log] if trainer.exchange is not None else "flat buckets"
+        result["allreduce_alone"] = allreduce_probe(model, trainer, dist, torch)
 
     if rank == 0 and not args.no_roofline:
         rt = model.rt
+        torch.cuda.synchronize()
+        rt.join_side()
+        # instrumented pass: ONE stream (no side stream — Runtime.call_side falls back while rt.profile is set — and no
+        # BEV-branch stream), HIP events on that stream around every C-ABI call: each kernel is timed running alone
         rt.profile = []
+        branch = rt.branch_streams
+        rt.branch_streams = False
         trainer.forward_backward(batch)          # no collective here: only rank 0 runs the instrumented pass
         model.params.adam_step(lr=1e-4)
         torch.cuda.synchronize()
+        rt.branch_streams = branch
         by = {}
         gemm_t = gemm_f = gemm_b = 0.0
         n_gemm = 0
@@ -221,6 +286,7 @@ def main():
         rt.profile = None
         achieved = gemm_f / (gemm_t * 1e-3) / 1e12
         traffic, traffic_src = pmc_hbm_bytes_per_gemm_launch()
+        result["build_id"] = __import__("multimodal_sc_amd.lib", fromlist=["lib"]).lib.msc_build_id().decode()
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                               "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gemm_b / max(n_gemm, 1),

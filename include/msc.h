@@ -34,6 +34,9 @@ enum { MSC_CH_AWGN = 0, MSC_CH_RAYLEIGH = 1 };
 
 const char* msc_strerror(int code);
 int msc_version(void);
+/* sha256 (hex, first 16 digits) of the kernel sources + msc.h this library was built from (csrc/Makefile embeds it), so
+   a test record can show that the loaded .so matches the checked-out sources */
+const char* msc_build_id(void);
 /* non-blocking HIP stream at a relative priority (-1 lowest, 0 default, +1 highest of the device's range); returns the
    hipStream_t as an integer, 0 on failure.  Used for the training step's side stream (weight gradients). */
 int64_t msc_stream_create(int level);
@@ -184,13 +187,16 @@ int msc_counter_add(int64_t* ctr, int64_t inc, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * SemanticEncoder power normalisation + Channel (AWGN / Rayleigh).  x,y: T [B][k]; noise/fading:
  * fp32 [B][k] or NULL (then Philox4x32-10 with `seed`); snr_db: fp32 [B]; scale: fp32 [B] (saved). */
-/* seed_dev (optional, device int64) is added to `seed` inside the kernel (per-step noise under hipGraph replay) */
+/* In-kernel noise: Philox4x32-10 with key = seed (lo, hi words; the host side puts the DP rank in the high word) and
+ * counter = (block lo, block hi, stream_id + 2*draw_hi, draw_lo).  draw_dev (optional, device int64): a draw counter the
+ * caller bumps (msc_counter_add) after every forward, read by the kernel — fresh noise per forward, also under hipGraph
+ * replay; seed, rank and draw never share a word, so (seed 1, draw 0) and (seed 0, draw 1) are different streams. */
 int msc_channel_fwd(const void* x, const float* noise, const float* fading, const float* snr_db, void* y,
-                    float* scale, int B, int k, int mode, uint64_t seed, const int64_t* seed_dev, int dtype,
+                    float* scale, int B, int k, int mode, uint64_t seed, const int64_t* draw_dev, int dtype,
                     void* stream);
 int msc_channel_bwd(const void* dy, const void* x, const float* scale, void* dx, int B, int k, int dtype,
                     void* stream);
-int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, void* stream);
+int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, uint64_t draw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LiDAR / BEV encoder front end: point MLP (4->64, ReLU) + scatter-max into [B][G][G][64]. */

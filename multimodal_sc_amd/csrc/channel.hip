@@ -4,15 +4,18 @@
 //   Rayleigh : symbols paired as complex, h = (hr + j*hi)/sqrt(2), y_c = h*s_c + sigma*n_c,
 //              receiver equalises with perfect CSI: out = y_c / h = s_c + sigma*n_c*conj(h)/|h|^2
 // Noise/fading come from explicit fp32 tensors (parity mode) or from an in-kernel counter-based
-// Philox4x32-10 keyed by (seed, sample*k/4 + quad) (throughput mode; oracle/philox.py restates it).
+// Philox4x32-10 (throughput mode; oracle/philox.py restates it): key = the 64-bit seed (the host puts the DP rank in its
+// high word), counter = (block index lo, hi, stream id | draw hi, draw lo) where `draw` is a device-side counter the
+// caller bumps after every forward — seed, rank and draw occupy separate words, so no two of them alias.
 // HBM-bound and tiny: one wave per sample row, one pass, wavefront-shuffle reductions.
 // Build-authored (the upstream reference has no code, SURVEY.md finding zero).
 #include "msc_common.h"
 
 // 4 standard normals from one Philox block (two Box-Muller pairs)
-__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t index, uint32_t stream_id, float (&z)[4]) {
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t index, uint32_t stream_id, uint64_t draw, float (&z)[4]) {
   uint32_t r[4];
-  philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream_id + 2u * (uint32_t)(draw >> 32), (uint32_t)draw, (uint32_t)seed,
+                (uint32_t)(seed >> 32), r);
   const float inv = 2.3283064365386963e-10f;  // 2^-32
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -32,8 +35,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void channel_fwd_kernel(const T* __restrict__ x, const float* __restrict__ noise,
                                                           const float* __restrict__ fading, const float* __restrict__ snr_db,
                                                           T* __restrict__ y, float* __restrict__ scale, int B, int k, int mode,
-                                                          uint64_t seed, const int64_t* __restrict__ seed_dev) {
-  if (seed_dev) seed += (uint64_t)*seed_dev;   // device-side step counter: fresh noise on every hipGraph replay
+                                                          uint64_t seed, const int64_t* __restrict__ draw_dev) {
+  // device-side draw counter (bumped by the caller after every forward, also under hipGraph replay): fresh noise per draw
+  const uint64_t draw = draw_dev ? (uint64_t)*draw_dev : 0ull;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -61,14 +65,14 @@ __global__ __launch_bounds__(256) void channel_fwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 4; ++j) n[j] = noise[(long)b * k + qi * 4 + j];
     } else {
-      philox_normal4(seed, (uint64_t)b * nq + qi, 0u, n);
+      philox_normal4(seed, (uint64_t)b * nq + qi, 0u, draw, n);
     }
     if (mode == MSC_CH_RAYLEIGH) {
       if (fading) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = fading[(long)b * k + qi * 4 + j];
       } else {
-        philox_normal4(seed, (uint64_t)b * nq + qi, 1u, h);
+        philox_normal4(seed, (uint64_t)b * nq + qi, 1u, draw, h);
       }
     }
 #pragma unroll
@@ -116,24 +120,24 @@ __global__ __launch_bounds__(256) void channel_bwd_kernel(const T* __restrict__ 
 }
 
 // raw generator output for tests: out[i*4..i*4+3] = 4 normals of Philox block i on `stream_id`
-__global__ void philox_fill_kernel(float* __restrict__ out, long nquads, uint64_t seed, uint32_t stream_id) {
+__global__ void philox_fill_kernel(float* __restrict__ out, long nquads, uint64_t seed, uint32_t stream_id, uint64_t draw) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (long)gridDim.x * blockDim.x) {
     float z[4];
-    philox_normal4(seed, (uint64_t)i, stream_id, z);
+    philox_normal4(seed, (uint64_t)i, stream_id, draw, z);
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[i * 4 + j] = z[j];
   }
 }
 
 extern "C" int msc_channel_fwd(const void* x, const float* noise, const float* fading, const float* snr_db, void* y, float* scale,
-                               int B, int k, int mode, uint64_t seed, const int64_t* seed_dev, int dtype, void* stream) {
+                               int B, int k, int mode, uint64_t seed, const int64_t* draw_dev, int dtype, void* stream) {
   MSC_CHECK_ARG(x && snr_db && y && scale && B > 0 && k > 0 && k % 4 == 0 && k <= 64 * 4 * CH_MAXQ);
   MSC_CHECK_ARG(mode == MSC_CH_AWGN || mode == MSC_CH_RAYLEIGH);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSC_F32)
-    hipLaunchKernelGGL(channel_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)x, noise, fading, snr_db, (float*)y, scale, B, k, mode, seed, seed_dev);
+    hipLaunchKernelGGL(channel_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)x, noise, fading, snr_db, (float*)y, scale, B, k, mode, seed, draw_dev);
   else if (dtype == MSC_BF16)
-    hipLaunchKernelGGL(channel_fwd_kernel<bf16_t>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const bf16_t*)x, noise, fading, snr_db, (bf16_t*)y, scale, B, k, mode, seed, seed_dev);
+    hipLaunchKernelGGL(channel_fwd_kernel<bf16_t>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const bf16_t*)x, noise, fading, snr_db, (bf16_t*)y, scale, B, k, mode, seed, draw_dev);
   else
     return MSC_ERR_BAD_ARG;
   return msc_launch_status();
@@ -160,10 +164,10 @@ extern "C" int msc_counter_add(int64_t* ctr, int64_t inc, void* stream) {
   return msc_launch_status();
 }
 
-extern "C" int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, void* stream) {
+extern "C" int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, uint64_t draw, void* stream) {
   MSC_CHECK_ARG(out && nquads > 0);
   long b = (nquads + 255) / 256;
   if (b > 2048) b = 2048;
-  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, out, (long)nquads, seed, stream_id);
+  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, out, (long)nquads, seed, stream_id, draw);
   return msc_launch_status();
 }

@@ -766,7 +766,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 // pixels give 100-200 tiles of 128x128 for 256 CUs, and 64-wide tiles run 4 MFMAs per barrier): 128x128 tiles over ns K
 // slices + the finish kernel above.  Returns 1 when the launch fills the chip or K is too short to split.
 static int plan_conv_split(long M, long N, long nk) {
-  static const int on = getenv("MSC_CONV_SPLITK") ? atoi(getenv("MSC_CONV_SPLITK")) : 1;   // A/B knob
+  const char* e = getenv("MSC_CONV_SPLITK");      // A/B + test knob, read per call so a test can switch it inside one process
+  const int on = e ? atoi(e) : 1;
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
   if (!on || tiles >= 200 || nk < 32 || N % 4) return 1;
   long ns = (400 + tiles / 2) / tiles;     // ~400 workgroups (measured: layer3 best at 2 slices, layer4 at 4)

@@ -164,42 +164,3 @@ extern "C" int msc_pillar_bwd(const float* points, const float* w, const float* 
   hipLaunchKernelGGL(pillar_bwd_finalize_kernel, dim3(cdiv(PIL_C * 5, 32)), dim3(1024), 0, st, ws, blocks, dw, db, accumulate);
   return msc_launch_status();
 }
-
-extern "C" const char* msc_strerror(int code) {
-  switch (code) {
-    case MSC_OK: return "ok";
-    case MSC_ERR_BAD_ARG: return "bad argument (null pointer, size or alignment the kernel does not support)";
-    case MSC_ERR_LAUNCH: return "HIP launch failed";
-    case MSC_ERR_UNSUPPORTED: return "unsupported configuration";
-    default: return "unknown error";
-  }
-}
-extern "C" int msc_version(void) { return 100; }
-
-// A non-blocking HIP stream at a priority level relative to the device's range: -1 lowest, 0 default, +1 highest.
-// Returns the hipStream_t as an integer (0 on failure).  The side stream of the training step (weight gradients, bias
-// column sums) is created at the lowest level so the dgrad / normalisation chain wins the CUs when both have work.
-extern "C" int64_t msc_stream_create(int level) {
-  int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 0;
-  const int prio = level < 0 ? least : (level > 0 ? greatest : 0);
-  hipStream_t st = nullptr;
-  if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) return 0;
-  return (int64_t)(intptr_t)st;
-}
-// One reusable event + "waiter waits for everything enqueued so far on signaler" (event record + stream wait).
-extern "C" int64_t msc_event_create(void) {
-  hipEvent_t ev = nullptr;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return 0;
-  return (int64_t)(intptr_t)ev;
-}
-extern "C" int msc_stream_wait_stream(void* waiter, void* signaler, int64_t event) {
-  hipEvent_t ev = (hipEvent_t)(intptr_t)event;
-  if (!ev) return MSC_ERR_BAD_ARG;
-  if (hipEventRecord(ev, (hipStream_t)signaler) != hipSuccess) return MSC_ERR_LAUNCH;
-  if (hipStreamWaitEvent((hipStream_t)waiter, ev, 0) != hipSuccess) return MSC_ERR_LAUNCH;
-  return MSC_OK;
-}
-extern "C" int msc_stream_destroy(int64_t stream) {
-  return hipStreamDestroy((hipStream_t)(intptr_t)stream) == hipSuccess ? MSC_OK : MSC_ERR_BAD_ARG;
-}

@@ -41,6 +41,8 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
     rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, gamma.p, beta.p, mean, rstd, stats[2], stats[3])
     y = rt.empty(B, Ho, Wo, Cout)
     rt.call("msc_bn_apply", y_raw, stats[2], stats[3], res, y, M, Cout, int(relu), rt.dt)
+    if rt.taps is not None and relu:
+        rt.taps[conv.name] = y
     return y, y_raw, mean, rstd
 
 
@@ -443,11 +445,11 @@ class MeanPool(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ channel
 class ChannelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rt, snr_db, noise, fading, mode, seed, seed_dev=None):
+    def forward(ctx, x, rt, snr_db, noise, fading, mode, seed, draw_dev=None):
         B, k = x.shape
         y = rt.empty(B, k)
         scale = rt.f32(B)
-        rt.call("msc_channel_fwd", x, noise, fading, snr_db, y, scale, B, k, mode, int(seed), seed_dev, rt.dt)
+        rt.call("msc_channel_fwd", x, noise, fading, snr_db, y, scale, B, k, mode, int(seed), draw_dev, rt.dt)
         ctx.save_for_backward(x, scale)
         ctx.rt = rt
         return y

@@ -144,7 +144,12 @@ class MultimodalSC:
         self._img_cut = int(os.environ.get("MSC_IMG_CUT", "3"))   # trunk layers below the backward boundary (0 = none)
         self._img_cut_out = self._img_cut_in = None
         self._bev_slot = None
+        # in-kernel channel noise (throughput mode): Philox key = (channel_seed, channel_rank), counter word = draw_dev, a
+        # device-side counter bumped after EVERY forward (training step, rollout or inference alike), so no two forwards
+        # and no two DP ranks see the same noise realisation; Trainer sets channel_rank from torch.distributed
         self.channel_seed = 0
+        self.channel_rank = 0
+        self.draw_dev = torch.zeros(1, dtype=torch.int64, device=self.rt.device)
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -311,7 +316,10 @@ class MultimodalSC:
         f = F.MeanPool.apply(x, rt)
         sym = self._lin(self._lin(f, "semantic_encoder.fc1", L.ACT_RELU), "semantic_encoder.fc2")
         mode = L.CH_AWGN if cfg.channel == "awgn" else L.CH_RAYLEIGH
-        rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, self.channel_seed, self.params.step_dev)
+        key = ((self.channel_rank & 0xFFFFFFFF) << 32) | (self.channel_seed & 0xFFFFFFFF)
+        rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, key, self.draw_dev)
+        if noise is None or (mode == L.CH_RAYLEIGH and fading is None):
+            rt.call("msc_counter_add", self.draw_dev, 1)      # the next forward draws fresh noise (also under hipGraph replay)
         z = self._lin(self._lin(rx, "semantic_decoder.fc1", L.ACT_RELU), "semantic_decoder.fc2")
         head = self._lin(self._lin(z, "head.fc", L.ACT_TANH), "head.out")
         g = cfg.recon_grid

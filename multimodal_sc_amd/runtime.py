@@ -44,6 +44,7 @@ class Runtime:
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
+        self.taps = None             # dict -> conv_bn_fwd records the post-ReLU output of every conv+BN+ReLU by weight name (tests)
         self.fused_attention = True  # bf16: flash-style kernel; False forces the batched-GEMM + softmax path (tests)
         self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
         self.side = None                   # second HIP stream for the weight-gradient GEMMs (call_side / join_side)
@@ -71,7 +72,9 @@ class Runtime:
         different streams and must not share reduction scratch.  per_stream=False: buffers only ever touched from the
         weight-gradient side stream."""
         n = (int(nbytes) + 3) // 4
-        key = (name, _raw_stream(self._dev_index) if per_stream else 0)
+        # per_stream=False is only safe while call_side() really routes to the side stream: when it falls back to the
+        # launching stream (MSC_SIDE_STREAM=0, instrumented pass) the main and BEV-branch streams would share the scratch
+        key = (name, _raw_stream(self._dev_index) if (per_stream or not self.side_active()) else 0)
         t = self._ws.get(key)
         if t is None or t.numel() < n:
             t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
@@ -95,12 +98,17 @@ class Runtime:
         self.profile.append((name, tuple(a for a in args if not hasattr(a, "data_ptr") and a is not None), e0, e1))
         return rc
 
+    def side_active(self):
+        """True when call_side() enqueues on the side stream (False: it falls back to the launching stream)"""
+        return self.wgrad_on_side and self.profile is None
+
     def call_side(self, name, *args):
         """Weight-gradient GEMMs are off the backward's critical path (nothing downstream reads them until the
         optimizer), and many of them cannot fill 256 CUs on their own: enqueue them on a second HIP stream so the
         hardware co-schedules them with the dgrad / normalisation chain on the main stream.  join_side() orders the main
-        stream behind them.  The instrumented (profile) pass stays on one stream for clean per-kernel timings."""
-        if not self.wgrad_on_side or self.profile is not None:
+        stream behind them.  The instrumented (profile) pass launches them on the calling stream (bench.py also turns the
+        BEV-branch stream off for that pass, so every timed kernel runs alone)."""
+        if not self.side_active():
             return self.call(name, *args)
         if self.side is None:
             self.side = self._make_side_stream()

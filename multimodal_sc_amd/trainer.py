@@ -1,25 +1,21 @@
 """Trainer.step: forward -> fused losses -> kernel backward chain -> DP gradient all-reduce (RCCL) -> fused Adam.
 
-Launch-bound host loop -> hipGraphs.  One training step is ~450 kernel launches on three HIP streams (main chain,
-weight-gradient side stream, LiDAR/BEV branch); issuing them from Python costs ~7 ms of host time against ~9 ms of GPU
-time, which both caps the step rate and starves the side streams of work to overlap.  After two eager warm-up steps
-(workspaces sized, lazy initialisation done) the step is captured once into hipGraphs and replayed:
+Host loop: EAGER multi-stream launches are the default.  One training step is a few hundred kernel launches on three
+HIP streams (main chain, weight-gradient side stream, LiDAR/BEV branch); the host enqueues them faster than the GPU
+executes them (tools/host_overhead.py), so the GPU never waits for Python.
+hipGraph capture of the step is implemented and bit-identical to eager, but OPT-IN (MSC_HIP_GRAPH=1) because it measured
+SLOWER on this stack (MI355X, ROCm 7.2, C3 @ 64 frames: replay 10.6 ms/step vs eager 9.7): the replay does not run the
+captured branches concurrently.  With the knob set, after two eager warm-up steps the step is captured once and replayed:
     world == 1 : ONE graph  = forward + losses + backward (both phases) + fused Adam
     world  > 1 : graph A    = forward + losses + upper backward (heads / codec / transformer)
-                 all-reduce of the upper gradients enqueued on RCCL's stream (async)
-                 graph B    = lower backward (ResNet-18 / BEV / state encoders) — overlaps that all-reduce
-                 all-reduce of the lower gradients, wait, graph C = fused Adam
-Step counter and channel-noise seed live in device memory (msc_counter_add), so a replay is a NEW step.  Inputs are
-static device buffers (a different batch is copied into them).  If capture fails the trainer falls back to eager
-launches.
-MEASURED (MI355X, ROCm 7.2, C3 @ 64 frames): replay 10.61 ms/step vs eager 9.66 ms/step, bit-identical results — the
-replay runs the three captured streams' branches no more concurrently than a single stream does (its time equals the
-eager time with the side streams disabled), while the eager host loop (7.2 ms of enqueue per step) still keeps ahead
-of the GPU.  The graph path is therefore OPT-IN (MSC_HIP_GRAPH=1); the default is eager multi-stream launches.
+                 all-reduce of the upper gradients (async), graph B = encoder backward under it,
+                 all-reduce of the encoder gradients, wait, graph C = fused Adam
+Step counter and channel-noise draw counter live in device memory (msc_counter_add), so a replay is a NEW step; inputs are
+static device buffers.  If capture fails the trainer falls back to eager launches, loudly.
 
 Data parallelism: one process per GPU, frames sharded over ranks (BatchNorm statistics stay per-GPU).  The only
 exchange step of the path is the gradient sum over the flat fp32 gradient buffer G, with torch.distributed (backend
-"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests) in two large pieces:
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests) in three large pieces (GradExchange below):
   upper  G[fusion.pos_embed:]  (transformer, semantic codec, heads: ~56 MB) — final after backward phase 1; its
          all-reduce runs under the whole encoder backward (phase 2);
   mid    G[layer4:fusion.pos_embed]  (top of the camera trunk, BEV branch, state encoder: ~40 MB) — final once the first
@@ -60,6 +56,49 @@ def allreduce_flat(flat: torch.Tensor, n_buckets: int = 4, group=None, async_op:
     return works
 
 
+class GradExchange:
+    """Slice bounds and issue order of the DP gradient sum over the flat buffer G — the only exchange step of the path.
+    Kept free of model and stream details so the schedule that ships can be driven by a fake backward on CPU tensors
+    (tests/test_dp_cpu.py, gloo): every rank must issue the same collectives over the same slices in the same order,
+    and the slices must tile [0, total) exactly once.
+        pieces >= 3 and mid is not None :  upper [split,total) -> mid [mid,split) -> rest [0,mid)
+        otherwise                        :  upper [split,total) -> rest [0,split)
+    `log` records (name, lo, hi) per issued collective."""
+
+    def __init__(self, total: int, split: int, mid=None, pieces: int = 3, group=None):
+        assert 0 < split <= total and (mid is None or 0 < mid < split)
+        self.total, self.split, self.group = total, split, group
+        self.mid = mid if pieces >= 3 else None
+        self.log = []
+        self._issued_mid = False
+
+    def bounds(self, name):
+        if name == "upper":
+            return self.split, self.total
+        if name == "mid":
+            assert self.mid is not None
+            return self.mid, self.split
+        assert name == "rest"
+        return 0, (self.mid if self._issued_mid else self.split)
+
+    def start(self, G, name):
+        """enqueue the asynchronous all-reduce (sum) of one piece on the CURRENT stream's ordering; returns the work handle"""
+        lo, hi = self.bounds(name)
+        if name == "mid":
+            self._issued_mid = True
+        self.log.append((name, lo, hi))
+        return dist.all_reduce(G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def begin_step(self):
+        self.log.clear()
+        self._issued_mid = False
+
+    def covered(self):
+        """True when the pieces issued since begin_step() tile [0, total) exactly once"""
+        iv = sorted((lo, hi) for _, lo, hi in self.log)
+        return bool(iv) and iv[0][0] == 0 and iv[-1][1] == self.total and all(a[1] == b[0] for a, b in zip(iv, iv[1:]))
+
+
 def _flatten(batch, prefix=""):
     for k, v in batch.items():
         if isinstance(v, dict):
@@ -75,11 +114,14 @@ class Trainer:
         self.n_buckets = n_buckets
         self.use_ppo = use_ppo
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            model.channel_rank = dist.get_rank()      # every rank draws its own channel noise (Philox key word)
         self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
         self.split = model.params.refs["fusion.pos_embed"].off
         self.use_graph = os.environ.get("MSC_HIP_GRAPH", "0") == "1"
         self.dp_pieces = int(os.environ.get("MSC_DP_PIECES", "3"))    # 2: upper + encoders; 3: upper + mid + rest of the trunk
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
+        self.exchange = None      # GradExchange, built on the first multi-rank step (needs the model's mid offset)
         self._seen = 0
         self._graphs = None       # (gA, gB, gC) once captured
         self._static = None       # the batch whose tensors the graphs read
@@ -102,7 +144,7 @@ class Trainer:
         terms = m.loss_and_grads(out, batch["image"], batch.get("ppo") if self.use_ppo else None)
         return out, terms
 
-    def _allreduce_mid(self, mid):
+    def _allreduce_mid(self):
         """all-reduce of G[mid:split] (top of the camera trunk, BEV branch, state encoder: ~41 of the 52 MB of encoder
         gradients) started while the rest of the trunk's backward is still being enqueued.  Its producers run on three
         streams (main, BEV branch, side).  The collective is issued with the BEV-branch stream current — that stream has
@@ -115,7 +157,7 @@ class Trainer:
         if rt.side is not None:
             s2.wait_stream(rt.side)
         with torch.cuda.stream(s2):
-            return dist.all_reduce(m.params.G[mid:self.split], op=dist.ReduceOp.SUM, async_op=True)
+            return self.exchange.start(m.params.G, "mid")
 
     def _adam(self):
         # the upper half of the parameters (transformer / codec / heads) is updated on the side stream: that update then
@@ -128,11 +170,16 @@ class Trainer:
             _, terms = self.forward_backward(batch)
         elif self.overlap:
             _, terms = self._forward_upper(batch)
-            works = [dist.all_reduce(G[self.split:], op=dist.ReduceOp.SUM, async_op=True)]
-            mid = m.mid_offset() if self.dp_pieces >= 3 else None
-            m.backward_lower(on_mid=(lambda: works.append(self._allreduce_mid(mid))) if mid is not None else None)
-            lo_end = mid if (mid is not None and len(works) == 2) else self.split
-            works.append(dist.all_reduce(G[:lo_end], op=dist.ReduceOp.SUM, async_op=True))
+            if self.exchange is None:
+                self.exchange = GradExchange(G.numel(), self.split, m.mid_offset(), self.dp_pieces)
+            ex = self.exchange
+            ex.begin_step()
+            works = [ex.start(G, "upper")]
+            # on_mid fires only when the encoder backward really ran its first two phases separately (C1 has no BEV
+            # branch: two pieces); "rest" then ends at mid, else at split — GradExchange.bounds tracks which
+            m.backward_lower(on_mid=(lambda: works.append(self._allreduce_mid())) if ex.mid is not None else None)
+            works.append(ex.start(G, "rest"))
+            assert ex.covered(), ex.log
             for w in works:
                 w.wait()
         else:
@@ -185,9 +232,10 @@ class Trainer:
         gA.replay()
         if self.world > 1:
             if gB is not None:
-                works = [dist.all_reduce(G[self.split:], op=dist.ReduceOp.SUM, async_op=True)]
+                ex = GradExchange(G.numel(), self.split, None, 2)
+                works = [ex.start(G, "upper")]
                 gB.replay()
-                works.append(dist.all_reduce(G[: self.split], op=dist.ReduceOp.SUM, async_op=True))
+                works.append(ex.start(G, "rest"))
             else:
                 works = allreduce_flat(G, self.n_buckets)
             for w in works:

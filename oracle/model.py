@@ -115,6 +115,18 @@ def _bn(x, w, b):
     return F.batch_norm(_r(x), None, None, w, b, True, 0.0, 1e-5)
 
 
+# ---- optional taps on the conv-stack ReLUs (tests only): with RELU_TAPS a dict, every ReLU that follows a BatchNorm
+# records its PRE-activation under the name of the convolution that feeds it (the product's parameter name), so a test can
+# locate elements whose sign differs between the two implementations (tests/test_model_gpu.py).  Default None = no-op.
+RELU_TAPS = None
+
+
+def _relu(x, tag):
+    if RELU_TAPS is not None:
+        RELU_TAPS[tag] = x.detach()
+    return F.relu(x)
+
+
 class BasicBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
@@ -123,16 +135,17 @@ class BasicBlock(nn.Module):
         self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(cout)
         self.downsample = None
+        self.tag = ""        # set by ImageEncoder: "image_encoder.layer<i>.<j>"
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, 0, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
         idt = x
-        out = _r(F.relu(_bn(self.conv1(x), self.bn1.weight, self.bn1.bias)))
+        out = _r(_relu(_bn(self.conv1(x), self.bn1.weight, self.bn1.bias), self.tag + ".conv1.weight"))
         out = _bn(self.conv2(out), self.bn2.weight, self.bn2.bias)
         if self.downsample is not None:
             idt = _r(_bn(self.downsample[0](x), self.downsample[1].weight, self.downsample[1].bias))
-        return _r(F.relu(out + idt))
+        return _r(_relu(out + idt, self.tag + ".conv2.weight"))
 
 
 class ImageEncoder(nn.Module):
@@ -146,9 +159,11 @@ class ImageEncoder(nn.Module):
         for i in range(1, 5):
             stride = 1 if i == 1 else 2
             setattr(self, f"layer{i}", nn.Sequential(BasicBlock(chans[i - 1], chans[i], stride), BasicBlock(chans[i], chans[i], 1)))
+            for j, blk in enumerate(getattr(self, f"layer{i}")):
+                blk.tag = f"image_encoder.layer{i}.{j}"
 
     def forward(self, img):
-        x = _r(F.relu(_bn(self.conv1(_r(img)), self.bn1.weight, self.bn1.bias)))
+        x = _r(_relu(_bn(self.conv1(_r(img)), self.bn1.weight, self.bn1.bias), "image_encoder.conv1.weight"))
         x = F.max_pool2d(x, 3, 2, 1)
         for i in range(1, 5):
             x = getattr(self, f"layer{i}")(x)
@@ -188,9 +203,9 @@ class BEVEncoder(nn.Module):
 
     def forward(self, points):
         g = _r(self.pillar_grid(points)).permute(0, 3, 1, 2)         # NCHW for torch convs
-        x = _r(F.relu(_bn(self.conv1(g), self.bn1.weight, self.bn1.bias)))
-        x = _r(F.relu(_bn(self.conv2(x), self.bn2.weight, self.bn2.bias)))
-        x = _r(F.relu(_bn(self.conv3(x), self.bn3.weight, self.bn3.bias)))
+        x = _r(_relu(_bn(self.conv1(g), self.bn1.weight, self.bn1.bias), "bev_encoder.conv1.weight"))
+        x = _r(_relu(_bn(self.conv2(x), self.bn2.weight, self.bn2.bias), "bev_encoder.conv2.weight"))
+        x = _r(_relu(_bn(self.conv3(x), self.bn3.weight, self.bn3.bias), "bev_encoder.conv3.weight"))
         return x  # [B,512,G/8,G/8]
 
 
@@ -440,26 +455,11 @@ def total_loss(out, image, cfg: MSCConfig, ppo=None):
 
 
 def synthetic_batch(cfg: MSCConfig, B: int, seed: int = 0, snr_db: float = 10.0):
-    """SURVEY.md §8d synthetic inputs, generated on CPU from a seeded torch.Generator."""
-    g = torch.Generator().manual_seed(seed)
-    b = {"image": torch.rand(B, 3, cfg.img_size, cfg.img_size, generator=g)}
-    if cfg.use_lidar:
-        xy = (torch.rand(B, cfg.n_points, 2, generator=g) * 2 - 1) * cfg.bev_range
-        z = torch.rand(B, cfg.n_points, 1, generator=g) * 4 - 3
-        it = torch.rand(B, cfg.n_points, 1, generator=g)
-        b["points"] = torch.cat([xy, z, it], -1)
-    if cfg.use_state:
-        b["state"] = torch.randn(B, cfg.state_dim, generator=g)
-    b["snr_db"] = torch.full((B,), float(snr_db))
-    b["noise"] = torch.randn(B, cfg.n_symbols, generator=g)
-    b["fading"] = torch.randn(B, cfg.n_symbols, generator=g)
-    b["ppo"] = {
-        "actions": torch.randint(0, cfg.n_actions, (B,), generator=g),
-        "old_logp": -math.log(cfg.n_actions) + 0.1 * torch.randn(B, generator=g),
-        "adv": torch.randn(B, generator=g),
-        "ret": torch.randn(B, generator=g),
-    }
-    return b
+    """SURVEY.md §8d synthetic inputs (seeded torch.Generator on the CPU).  The generator lives in the product package
+    (multimodal_sc_amd/synthetic.py: no model code) so bench.py's GPU leg needs nothing from oracle/; both sides of every
+    parity test draw identical frames from it."""
+    from multimodal_sc_amd.synthetic import synthetic_batch as gen
+    return gen(cfg, B, seed, snr_db)
 
 
 def build_oracle(cfg: MSCConfig, seed: int = 0) -> MultimodalSC:

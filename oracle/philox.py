@@ -27,12 +27,14 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def philox_normal(nquads: int, seed: int, stream_id: int) -> np.ndarray:
-    """-> float32 [nquads*4]: block i gives 4 normals (two Box-Muller pairs), as msc_philox_normal does."""
+def philox_normal(nquads: int, seed: int, stream_id: int, draw: int = 0) -> np.ndarray:
+    """-> float32 [nquads*4]: block i gives 4 normals (two Box-Muller pairs), as msc_philox_normal does.
+    key = seed (lo, hi); counter = (i lo, i hi, stream_id + 2*draw_hi, draw_lo): the draw counter of the Channel layer."""
     idx = np.arange(nquads, dtype=np.uint64)
     z = np.zeros(nquads, dtype=np.uint32)
+    c2 = np.uint32((stream_id + 2 * (draw >> 32)) & 0xFFFFFFFF)
     r = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32),
-                      z + np.uint32(stream_id), z, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+                      z + c2, z + np.uint32(draw & 0xFFFFFFFF), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     inv = np.float32(2.3283064365386963e-10)
     out = np.empty((nquads, 4), dtype=np.float32)
     for i in range(2):

@@ -1,0 +1,41 @@
+"""Child process of tests/test_dp_gpu.py: one data-parallel rank running Trainer.step on cuda:0.
+usage: python dp_worker.py <rank> <world> <port> <out.pt> <config> <frames> <steps>
+Ranks share the one GPU of the test box and exchange gradients through gloo (host memory) — the same Trainer code path
+the real runs take over RCCL, one rank per GPU.  Schedule knobs (MSC_DP_PIECES, MSC_DP_OVERLAP) come from the environment."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out, cfg_name, B, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    import torch
+    import torch.distributed as dist
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from multimodal_sc_amd.synthetic import synthetic_batch
+    from multimodal_sc_amd.trainer import Trainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = named_config(cfg_name)
+    m = MultimodalSC(cfg, dtype="bf16", device="cuda:0", seed=0)          # same seed: identical initial parameters
+    tr = Trainer(m, lr=1e-3)
+    cb = synthetic_batch(cfg, B, seed=100 + rank)                           # each rank its own shard of frames
+    gb = {k: (v.to("cuda:0") if torch.is_tensor(v) else v) for k, v in cb.items() if k != "ppo"}
+    gb["ppo"] = {k: v.to("cuda:0") for k, v in cb["ppo"].items()}
+    for _ in range(steps):
+        tr.step(gb)
+    torch.cuda.synchronize()
+    m.rt.join_side()
+    torch.cuda.synchronize()
+    log = list(tr.exchange.log) if tr.exchange is not None else []
+    torch.save({"P": m.params.P.cpu(), "G": m.params.G.cpu(), "log": log}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""The data-parallel path that ships, on the GPU: two ranks (fresh child processes sharing cuda:0, gradients exchanged
+through gloo) run Trainer.step — three-piece overlapped all-reduce with the mid piece issued from the BEV-branch stream,
+side-stream Adam split — and must end with
+  * parameters bit-identical across ranks (the property DP needs),
+  * parameters AND reduced gradients bit-identical across the three schedules: 3 pieces (default), 2 pieces
+    (MSC_DP_PIECES=2) and the non-overlapped bucketed all-reduce (MSC_DP_OVERLAP=0) — a missed stream dependency in the
+    overlapped schedule would sum a partial gradient and show up here, while the ranks would still agree with each other.
+With two ranks a+b is exact in any order, so every comparison is bitwise.  (SURVEY.md §4 'DP all-reduce'.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_world(tmp_path, tag, env_extra, cfg="C3", frames=2, steps=3, world=2):
+    port = str(_free_port())
+    env = dict(os.environ, **env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    outs = [str(tmp_path / f"{tag}_r{r}.pt") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, outs[r], cfg,
+                               str(frames), str(steps)], env=env) for r in range(world)]
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs == [0] * world, (tag, rcs)
+    return [torch.load(o, weights_only=True) for o in outs]
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C1"])
+def test_overlapped_dp_step_matches_other_schedules(cuda, tmp_path, cfg):
+    runs = {"p3": _run_world(tmp_path, "p3", {"MSC_DP_PIECES": "3", "MSC_DP_OVERLAP": "1"}, cfg),
+            "p2": _run_world(tmp_path, "p2", {"MSC_DP_PIECES": "2", "MSC_DP_OVERLAP": "1"}, cfg),
+            "flat": _run_world(tmp_path, "flat", {"MSC_DP_OVERLAP": "0"}, cfg)}
+    for tag, rs in runs.items():
+        assert torch.isfinite(rs[0]["P"]).all(), tag
+        assert torch.equal(rs[0]["P"], rs[1]["P"]), f"{tag}: parameters differ across ranks"
+        assert torch.equal(rs[0]["G"], rs[1]["G"]), f"{tag}: reduced gradients differ across ranks"
+    want = ["upper", "mid", "rest"] if cfg == "C3" else ["upper", "rest"]      # C1: no BEV branch -> no mid piece
+    assert [n for n, _, _ in runs["p3"][0]["log"]] == want
+    assert [n for n, _, _ in runs["p2"][0]["log"]] == ["upper", "rest"]
+    for tag in ("p2", "flat"):
+        assert torch.equal(runs["p3"][0]["G"], runs[tag][0]["G"]), f"3-piece vs {tag}: reduced gradients differ"
+        assert torch.equal(runs["p3"][0]["P"], runs[tag][0]["P"]), f"3-piece vs {tag}: parameters differ"

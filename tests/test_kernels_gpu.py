@@ -192,13 +192,27 @@ CONV_CASES = [  # B,H,W,Cin,Cout,K,stride,pad
 ]
 
 
+# cases that MUST take the split-K path (forward and, being stride 1, dgrad) / the case that must NOT, in both dtypes:
+# the strict per-kernel tolerances below therefore cover plan_conv_split + splitk_finish, not only the un-split kernel
+CONV_SPLIT_CASES = {(3, 7, 7, 256, 512, 3, 1, 1), (8, 1, 1, 512, 512, 3, 1, 1)}
+CONV_UNSPLIT_CASES = {(2, 16, 16, 8, 64, 7, 2, 3), (2, 14, 14, 64, 128, 1, 2, 0)}
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("relu", [True, False])
 def test_conv_bn_fwd_bwd(rts, dtype, case, relu):
-    from multimodal_sc_amd import functional as F
+    from multimodal_sc_amd import functional as F, lib as L
     rt = rts[dtype]
     B, H, W, Cin, Cout, K, s, p = case
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    wsb_f = L.query("msc_conv2d_splitk_workspace_bytes", B * Ho * Wo, Cout, K * K * Cin, rt.dt)
+    wsb_d = L.query("msc_conv2d_splitk_workspace_bytes", B * H * W, Cin, K * K * Cout, rt.dt)
+    if case in CONV_SPLIT_CASES:
+        assert wsb_f > 0 and wsb_d > 0, "this case is meant to exercise the split-K convolution path"
+        assert wsb_f % (B * Ho * Wo * Cout * 4) == 0 and wsb_f // (B * Ho * Wo * Cout * 4) >= 2
+    if case in CONV_UNSPLIT_CASES:
+        assert wsb_f == 0, "this case is meant to exercise the un-split kernel"
     x = rnd(B, H, W, Cin, seed=1)
     w = rnd(Cout, K, K, Cin, seed=2, scale=1 / math.sqrt(K * K * Cin))
     gamma, beta = 1 + 0.1 * rnd(Cout, seed=3), 0.1 * rnd(Cout, seed=4)
@@ -392,7 +406,7 @@ def test_channel_power_and_snr(rts):
         assert abs(meas - snr_db) < 0.1, (meas, snr_db)
     # Rayleigh: E|h|^2 = 1 from the fading stream
     z = rt.f32(1 << 20)
-    rt.call("msc_philox_normal", z, (1 << 20) // 4, 77, 1)
+    rt.call("msc_philox_normal", z, (1 << 20) // 4, 77, 1, 0)
     h2 = (z.view(-1, 2) / math.sqrt(2)).pow(2).sum(-1).mean()
     assert abs(float(h2) - 1.0) < 1e-2
 
@@ -402,9 +416,47 @@ def test_philox_matches_cpu_restatement(rts):
     rt = rts["f32"]
     nq = 1000
     z = rt.f32(nq * 4)
-    rt.call("msc_philox_normal", z, nq, 0x123456789ABCDEF, 1)
+    rt.call("msc_philox_normal", z, nq, 0x123456789ABCDEF, 1, 0)
     ref = torch.from_numpy(philox_normal(nq, 0x123456789ABCDEF, 1))
     check("philox", z, ref, 2e-5)
+    # the draw counter (bumped per forward) and the rank word of the key select independent streams, none aliasing another
+    for seed, draw in ((0x123456789ABCDEF, 5), (7, (3 << 32) | 9), ((1 << 32) | 7, 0)):
+        rt.call("msc_philox_normal", z, nq, seed, 0, draw)
+        check(f"philox seed={seed:#x} draw={draw:#x}", z, torch.from_numpy(philox_normal(nq, seed, 0, draw)), 2e-5)
+    outs = []
+    for seed, draw in ((0, 1), (1, 0), (1 << 32, 0), (0, 0)):      # (seed 0, draw 1) must differ from (seed 1, draw 0)
+        rt.call("msc_philox_normal", z, nq, seed, 0, draw)
+        outs.append(z.clone())
+    for i in range(len(outs)):
+        for j in range(i):
+            assert not torch.equal(outs[i], outs[j]), (i, j)
+
+
+def test_channel_noise_fresh_per_forward_and_per_rank(rts):
+    """in-kernel noise: the draw counter feeds a Philox counter word, so consecutive forwards (rollouts, inference) and
+    different DP ranks (key word) see different realisations; the same (seed, rank, draw) reproduces bit for bit."""
+    from multimodal_sc_amd import lib as L
+    rt = rts["f32"]
+    B, k = 8, 256
+    x = (rnd(B, k, seed=1) * 2).to(rt.device)
+    snr = torch.full((B,), 5.0, device=rt.device)
+    draw = torch.zeros(1, dtype=torch.int64, device=rt.device)
+
+    def run(seed):
+        y, scale = rt.f32(B, k), rt.f32(B)
+        rt.call("msc_channel_fwd", x, None, None, snr, y, scale, B, k, L.CH_RAYLEIGH, seed, draw, rt.dt)
+        return y
+
+    a0 = run(3)
+    rt.call("msc_counter_add", draw, 1)
+    a1 = run(3)
+    r1 = run((1 << 32) | 3)                  # rank 1, same draw
+    draw.zero_()
+    b0 = run(3)
+    torch.cuda.synchronize()
+    assert torch.equal(a0, b0)
+    assert not torch.equal(a0, a1) and not torch.equal(a1, r1)
+    assert (a0 - a1).abs().mean() > 0.1
 
 
 # ------------------------------------------------------------------------------------------------ pillars

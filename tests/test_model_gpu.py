@@ -41,13 +41,18 @@ def _oracle_run(om, batch, ocfg, ppo=True):
     return out, {k: float(v.detach()) for k, v in terms.items()}
 
 
-def _run_pair(name, B, dtype, ppo=True, with_f64=False):
+def _run_pair(name, B, dtype, ppo=True, with_f64=False, snr_db=10.0, taps=False):
     from multimodal_sc_amd.model import MultimodalSC, named_config
     from oracle import model as O
     ocfg, cfg = O.named_config(name), named_config(name)
     om = O.build_oracle(ocfg, seed=1)
-    batch = O.synthetic_batch(ocfg, B, seed=2)
-    oout, oterms = _oracle_run(om, batch, ocfg, ppo)
+    batch = O.synthetic_batch(ocfg, B, seed=2, snr_db=snr_db)
+    otaps = {} if taps else None
+    O.RELU_TAPS = otaps
+    try:
+        oout, oterms = _oracle_run(om, batch, ocfg, ppo)
+    finally:
+        O.RELU_TAPS = None
     g64 = None
     if with_f64:
         om64 = copy.deepcopy(om).double()
@@ -55,27 +60,92 @@ def _run_pair(name, B, dtype, ppo=True, with_f64=False):
         g64 = {k: p.grad for k, p in om64.named_parameters()}
     m = MultimodalSC(cfg, dtype=dtype, device="cuda:0")
     m.load_oracle_state_dict(om.state_dict())
+    if taps:
+        m.rt.taps = {}
     gb = _to(m.rt.device, batch)
     out = m(gb["image"], gb.get("points"), gb.get("state"), gb["snr_db"], gb["noise"], gb["fading"])
     terms = m.loss_and_grads(out, gb["image"], gb["ppo"] if ppo else None)
     torch.cuda.synchronize()
+    if taps:
+        return om, oout, oterms, m, out, terms, batch, g64, otaps
     return om, oout, oterms, m, out, terms, batch, g64
 
 
-@pytest.mark.parametrize("name,B", [("C0", 8), ("C3", 2), ("C4", 2)])
-def test_f32_end_to_end_parity(cuda, name, B):
-    """C4 = Rayleigh channel + e4m3 semantic encoder/decoder GEMMs: an activation that sits within fp32 rounding of an
+def _conv_order(cfg):
+    """forward order of the conv+BN(+ReLU) layers of each encoder branch, by the weight name that tags their ReLU"""
+    img = ["image_encoder.conv1.weight"]
+    for li in range(1, 5):
+        for bi in range(2):
+            img += [f"image_encoder.layer{li}.{bi}.conv1.weight", f"image_encoder.layer{li}.{bi}.conv2.weight"]
+    bev = [f"bev_encoder.conv{i}.weight" for i in (1, 2, 3)] if cfg.use_lidar else []
+    return img, bev
+
+
+def _layer_tag_of_param(k):
+    """parameter name -> tag of the ReLU its layer feeds (None outside the conv stacks)"""
+    if k.startswith("bev_encoder.point_mlp"):
+        return "bev_encoder.conv1.weight"          # upstream of the whole BEV conv stack
+    if k.startswith("bev_encoder."):
+        i = k.split(".")[1][-1]
+        return f"bev_encoder.conv{i}.weight"
+    if not k.startswith("image_encoder."):
+        return None
+    parts = k.split(".")
+    if parts[1] in ("conv1", "bn1"):
+        return "image_encoder.conv1.weight"
+    blk = ".".join(parts[:3])
+    which = parts[3]
+    if which in ("conv1", "bn1"):
+        return blk + ".conv1.weight"
+    return blk + ".conv2.weight"                   # conv2, bn2 and the downsample branch all end in the block-output ReLU
+
+
+def _relu_flips(m, otaps):
+    """elements whose ReLU mask differs between the HIP path and the oracle, per ReLU: {tag: (count, max |pre-activation|
+    of the oracle at those elements relative to the tensor's max)}.  Such an element is a pre-activation within fp32
+    rounding of zero that landed on the other side in the two summation orders."""
+    flips = {}
+    for tag, pre in otaps.items():
+        y = m.rt.taps[tag].float().cpu()                       # NHWC, post-ReLU
+        pre = pre.permute(0, 2, 3, 1)
+        diff = (y > 0) != (pre > 0)
+        n = int(diff.sum())
+        if n:
+            flips[tag] = (n, float(pre[diff].abs().max() / pre.abs().max()))
+    return flips
+
+
+F32_CASES = [("C0", 8, 10.0, "1"), ("C1", 2, 10.0, "1"), ("C2", 2, 10.0, "1"), ("C3", 2, 10.0, "1"), ("C3", 2, 10.0, "0"),
+             ("C4", 2, 10.0, "1"), ("C4", 2, -5.0, "1"), ("C4", 2, 5.0, "1"), ("C4", 2, 15.0, "1")]
+
+
+@pytest.mark.parametrize("name,B,snr_db,splitk", F32_CASES)
+def test_f32_end_to_end_parity(cuda, monkeypatch, name, B, snr_db, splitk):
+    """Every named single-GPU configuration (C0..C4; C4 over the SNR sweep of configs[4]) against the fp32 oracle.
+    splitk = MSC_CONV_SPLITK: C3 also runs with the split-K convolutions switched off — both runs are held to the SAME
+    criterion, so nothing about it depends on split-K.
+    C4 = Rayleigh channel + e4m3 semantic encoder/decoder GEMMs: an activation that sits within fp32 rounding of an
     e4m3 rounding boundary may quantise one grid step (6 %) apart in the two implementations, so C4 compares the
-    codec-dependent tensors at 2e-2 instead of 1e-3 (one flipped element moves a 512-term dot product by ~4e-3) (PSNR and the bit-exact action check are unchanged)."""
+    codec-dependent tensors at 2e-2 instead of 1e-3 (one flipped element moves a 512-term dot product by ~4e-3) (PSNR and the bit-exact action check are unchanged).
+    Gradient criterion (all but C4): every parameter tensor within 5x the fp32 oracle's own error against its fp64 run.
+    A tensor may miss that bound ONLY if a ReLU-mask flip is PROVEN in its own layer or downstream of it: an element of a
+    conv-stack ReLU whose mask differs between the two implementations, with an oracle pre-activation below 1e-5 of the
+    tensor's maximum (i.e. zero to fp32 rounding) — at most 2 such elements per ReLU.  At 2 frames one flipped element of
+    layer4 (98 samples per channel) moves every gradient upstream of it by ~1 %; those tensors are then held to 2 %
+    relative Frobenius error and the whole gradient to cosine > 0.9995.  No proven flip -> no loosening."""
+    from multimodal_sc_amd.model import named_config
     from oracle import model as O
-    om, oout, oterms, m, out, terms, batch, g64 = _run_pair(name, B, "f32", with_f64=True)
+    monkeypatch.setenv("MSC_CONV_SPLITK", splitk)
+    om, oout, oterms, m, out, terms, batch, g64, otaps = _run_pair(name, B, "f32", with_f64=True, snr_db=snr_db, taps=True)
     logits, value = m.logits_value(out)
     t = 2e-2 if name == "C4" else 1e-3
     gslack = 2e-2 if name == "C4" else 5e-4
     assert (logits.cpu() - oout["logits"]).abs().max() < t
     assert (value.cpu() - oout["value"]).abs().max() < t
     assert (out["symbols"].float().cpu() - oout["symbols"]).abs().max() < t
-    assert (out["rx"].float().cpu() - oout["rx"]).abs().max() < t * (10 if name == "C4" else 1)   # Rayleigh: equalised by 1/|h|^2
+    # Rayleigh: equalised by 1/|h|^2; the noise term scales with sigma = 10^(-snr/20), so low SNR widens the absolute bound
+    rx_t = t * (10 if name == "C4" else 1) * max(1.0, 10 ** (-snr_db / 20.0))
+    assert (out["rx"].float().cpu() - oout["rx"]).abs().max() < rx_t
     assert (m.recon_image(out).cpu() - oout["recon"]).abs().max() < t
     met = m.metrics(terms)
     opsnr = O.psnr(oout["recon"], batch["image"]).mean().item()
@@ -83,8 +153,25 @@ def test_f32_end_to_end_parity(cuda, name, B):
     assert torch.equal(m.select_action(out).cpu(), O.select_action(oout["logits"]))   # actions bit-exact
     for k in ("mse", "policy", "value", "entropy", "loss"):
         assert abs(met[k] - oterms[k]) < (t / 10) * max(1.0, abs(oterms[k])), (k, met[k], oterms[k])
+    # ---- ReLU-mask flips: located, counted, and shown to be zero-to-rounding pre-activations
+    assert set(otaps) == set(m.rt.taps), (sorted(otaps), sorted(m.rt.taps))
+    flips = _relu_flips(m, otaps)
+    for tag, (n, mag) in flips.items():
+        assert n <= 2 and mag < 1e-5, ("ReLU masks differ beyond rounding", tag, n, mag)
+    img_order, bev_order = _conv_order(named_config(name))
+    last = {}                                          # branch -> index of the LAST (closest to the loss) flipped ReLU
+    for br, order in (("img", img_order), ("bev", bev_order)):
+        idx = [order.index(tg) for tg in flips if tg in order]
+        last[br] = max(idx) if idx else -1
+
+    def flip_downstream_of(k):
+        tag = _layer_tag_of_param(k)
+        if tag is None:
+            return False
+        br, order = ("bev", bev_order) if tag.startswith("bev") else ("img", img_order)
+        return order.index(tag) <= last[br]
     gg = m.export_state_dict(grads=True)
-    bad, flipped = [], []
+    bad, loosened = [], []
     for k, p in om.named_parameters():
         ref64 = g64[k]
         if name == "C4":
@@ -103,21 +190,17 @@ def test_f32_end_to_end_parity(cuda, name, B):
         e_f32 = (p.grad.double() - ref64).abs().max().item()
         bound = 5 * e_f32 + gslack * den + 1e-12
         if e_gpu > bound:
-            # A pre-activation within fp32 rounding of zero can land on the other side of its ReLU than in the oracle (any
-            # change of summation order — tile shape, split-K — moves which element that is).  At 2 frames ONE flipped
-            # element of layer4's output mask (98 samples per channel) shifts every gradient upstream of it by ~1 %: not an
-            # implementation error, and no element-wise bound survives it.  Tensors that miss the strict bound must then
-            # stay within 2 % relative Frobenius error, and the whole gradient must keep its direction (checked below); the
-            # kernels themselves are held to the strict per-kernel bounds of test_kernels_gpu.py.
             relf = (err.norm() / ref64.norm().clamp_min(1e-300)).item()
-            flipped.append(k)
-            if relf > 2e-2:
-                bad.append((k, e_gpu / max(den, 1e-30), e_f32 / max(den, 1e-30), relf))
-    assert not bad, bad[:8]
-    if flipped:
+            if flip_downstream_of(k) and relf <= 2e-2:
+                loosened.append(k)
+            else:
+                bad.append((k, e_gpu / max(den, 1e-30), e_f32 / max(den, 1e-30), relf, "flip proven" if flip_downstream_of(k) else "NO flip"))
+    print(f"[{name} snr={snr_db} splitk={splitk}] relu flips: {flips}; tensors on the loose bound: {len(loosened)}")
+    assert not bad, (bad[:8], flips)
+    if loosened:
         a = torch.cat([gg[k].double().flatten() for k in g64])
         b = torch.cat([g64[k].flatten() for k in g64])
-        assert (a @ b / (a.norm() * b.norm())).item() > 0.9995, flipped[:8]
+        assert (a @ b / (a.norm() * b.norm())).item() > 0.9995, loosened[:8]
 
 
 def test_bf16_forward_parity_c0(cuda):
@@ -173,23 +256,47 @@ def test_bf16_end_to_end_parity_c3(cuda):
     assert all(a > b - 0.02 for a, b, _ in rows), [r for r in rows if r[0] <= r[1] - 0.02]
 
 
-@pytest.mark.parametrize("B", [2, 64])
-def test_determinism_bitwise(cuda, B):
+@pytest.mark.parametrize("name,B", [("C3", 2), ("C3", 64), ("C1", 64), ("C2", 64)])
+def test_determinism_bitwise(cuda, name, B):
     """run the same step twice: every output and every gradient must be bit-identical (no float atomics anywhere) — also
-    at the full benchmark batch (64 frames), where split-K slices, three streams and every tile shape are in play."""
+    at the full benchmark batch (64 frames), where split-K slices, three streams and every tile shape are in play.
+    C1 (camera only: T=49 tokens, no BEV stream, single-stream schedule) and C2 (no ego-state token) run here as named
+    configurations at their BASELINE.json batch of 64 bf16 frames; their outputs must also be finite and their PSNR sane."""
     from multimodal_sc_amd.model import MultimodalSC, named_config
     from oracle import model as O
-    m = MultimodalSC(named_config("C3"), dtype="bf16", device="cuda:0", seed=3)
-    gb = _to(m.rt.device, O.synthetic_batch(O.named_config("C3"), B, seed=5))
+    m = MultimodalSC(named_config(name), dtype="bf16", device="cuda:0", seed=3)
+    gb = _to(m.rt.device, O.synthetic_batch(O.named_config(name), B, seed=5))
     res = []
     for _ in range(2):
-        out = m(gb["image"], gb["points"], gb["state"], gb["snr_db"], gb["noise"], gb["fading"])
+        out = m(gb["image"], gb.get("points"), gb.get("state"), gb["snr_db"], gb["noise"], gb["fading"])
         m.loss_and_grads(out, gb["image"], gb["ppo"])
         torch.cuda.synchronize()
         res.append((out["head"].clone(), out["patches"].clone(), m.params.G.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
-    assert torch.isfinite(res[0][2]).all()
+    assert torch.isfinite(res[0][2]).all() and torch.isfinite(res[0][0].float()).all()
+    assert res[0][2].abs().max() > 0
+
+
+def test_inkernel_noise_differs_between_forwards_and_ranks(cuda):
+    """throughput mode (noise=None): every forward draws fresh channel noise (device-side draw counter), and two models
+    that differ only in channel_rank (what Trainer sets from the DP rank) draw different noise for the same frames."""
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from oracle import model as O
+    cfg = named_config("C0")
+    batch = O.synthetic_batch(O.named_config("C0"), 8, seed=5)
+    rx = []
+    for rank in (0, 1):
+        m = MultimodalSC(cfg, dtype="f32", device="cuda:0", seed=3)
+        m.channel_rank = rank
+        d = m.rt.device
+        with torch.no_grad():
+            for _ in range(2):
+                out = m(batch["image"].to(d), None, None, batch["snr_db"].to(d), None, None)
+                rx.append(out["rx"].clone())
+    torch.cuda.synchronize()
+    assert not torch.equal(rx[0], rx[1]), "two consecutive forwards saw the same noise"
+    assert not torch.equal(rx[0], rx[2]) and not torch.equal(rx[1], rx[3]), "rank 0 and rank 1 drew the same noise"
 
 
 def test_training_reduces_loss(cuda):
