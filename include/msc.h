@@ -52,9 +52,9 @@ int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t re
  * ImageEncoder / BEV conv stack: implicit-GEMM convolution (no im2col buffer).
  * x:[B,H,W,Cin] w:[Cout,KH,KW,Cin] y:[B,Ho,Wo,Cout], Ho=(H+2p-KH)/s+1.  Cin must be a power of two
  * >= 16/sizeof(T) (the RGB image is padded to 8 channels by msc_image_to_nhwc).
- * bn_partial (may be NULL): fp32 [msc_conv2d_fwd_stat_rows(B*Ho*Wo, Cout)][2][Cout] per-row-block column
+ * bn_partial (may be NULL): fp32 [msc_conv2d_fwd_stat_rows(B*Ho*Wo, Cout, dtype)][2][Cout] per-row-block column
  * sums / sums of squares of the fp32 accumulators, reduced in fixed order by msc_bn_finalize (deterministic). */
-int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout);
+int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout, int dtype);
 /* ws / ws_bytes (may be NULL / 0): fp32 scratch of msc_conv2d_splitk_workspace_bytes(rows_out, cols_out, k_len, dtype)
  * bytes.  Launches that cannot fill the chip (deep layers: few output rows, long K) then run as split-K over 128x128
  * tiles + a fixed-order finish kernel that also writes bn_partial; without the workspace the un-split kernel runs.
@@ -82,9 +82,9 @@ int msc_linear_fwd(const void* x, const void* w, const float* bias, const void* 
 /* dx[M,K] = (dy[M,N] wt[K,N]^T) * act'(dact_ref[M,K])   (wt = w transposed, [K][N] row-major).
  * dact_ref/dact (optional): fused backward of the activation that FED this layer — dact_ref is that activation's
  * output (relu/tanh/sigmoid) or pre-activation (gelu); dx is then the gradient w.r.t. the previous layer's
- * pre-activation.  colsum_partial (optional): fp32 [msc_linear_dgrad_colsum_rows(M,K)][K] per-row-block column sums
+ * pre-activation.  colsum_partial (optional): fp32 [msc_linear_dgrad_colsum_rows(M,K,dtype)][K] per-row-block column sums
  * of dx (= the previous layer's bias gradient after msc_colsum_finalize). */
-int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K);
+int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K, int dtype);
 int msc_linear_dgrad(const void* dy, const void* wt, const void* dact_ref, int dact, float* colsum_partial, void* dx,
                      int M, int N, int K, int dtype, void* stream);
 int msc_colsum_finalize(const float* partial, int nblk, int64_t cols, float* out, int accumulate, void* stream);

@@ -8,17 +8,20 @@
 //   OPM_CONV_WGRAD  B = NHWC activations gathered, reduction k=(b,ho,wo), rows n=(kh,kw,cin)
 // so convolution is an implicit GEMM: there is no im2col buffer in HBM.
 //
-// Tile 128 x BN (BN = 128 | 64) x 64 bytes of K per step; 256 threads = 4 waves (2x2), each wave owns 64 x BN/2 as
-// 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16; exact-fp32 v_mfma_f32_32x32x2_f32 in parity mode).
+// Tiles BM x BN in {64,128}^2 (4 waves, 2x2), 256x128 (8 waves, 4x2) and 256x256 (8 waves, 2x4), 128 BYTES of K per
+// operand row per step (64 bf16 / 32 fp32 elements): every LDS-DMA instruction moves 8 rows x one full 128-byte cache line
+// (half-line pieces cost the same address/tag work for half the bytes).  Waves own WM x WN as 32x32 MFMA tiles
+// (v_mfma_f32_32x32x16_bf16; exact-fp32 v_mfma_f32_32x32x2_f32 in parity mode).
 //
 // Staging (gfx950): operands go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, no
 // VGPR round trip).  The per-lane SOURCE offset does the gather (implicit-GEMM taps, transposition-free weight
 // gradients) and the XOR bank swizzle (the LDS image itself is lane-linear, as the hardware requires); lanes whose
 // element is padding / out of range use an out-of-range buffer offset, which the hardware turns into zeros in LDS.
-//   k-major operands : LDS rows of 64 B, chunk c of row r at c ^ ((r>>2)&3)      -> conflict-free ds_read_b128
+//   k-major operands : LDS rows of 128 B, chunk c of row r at c ^ ((r>>1)&7)     -> conflict-free ds_read_b128
 //   mn-major operands: LDS image [k][row] as it lies in HBM, chunk ^ swizzle(k)  -> ds_read_b64_tr_b16 (hardware
 //                      transpose) builds the MFMA fragment; no transposing pass anywhere (bf16).
-// Two LDS buffers: the DMA of K-step t+1 is in flight while the MFMAs of step t run; one barrier per K step.
+// 2-3 LDS stages (by tile, see STAGES): the DMA of K-steps t+1.. is in flight while the MFMAs of step t run; one barrier
+// per K step (16-32 MFMAs per wave).
 // The exact-fp32 parity mode has no transposed LDS read, so its mn-major operands are staged through registers and
 // transposed on the LDS write (correctness path, not tuned).
 // Workgroup ids are remapped so that the tiles sharing an activation row-block run on one XCD (shared L2).
@@ -27,6 +30,7 @@
 // ImageEncoder/BEV conv stack, FusionTransformer, SemanticEncoder/Decoder, heads.
 #include "msc_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 enum { OPM_DENSE_K = 0, OPM_DENSE_MN = 1, OPM_CONV_FWD = 2, OPM_CONV_DGRAD = 3, OPM_CONV_WGRAD = 4 };
 
@@ -40,6 +44,8 @@ struct GemmParams {
   // geometry of the gathered NHWC tensor (conv modes)
   int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
   int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
+  unsigned long long* stamps;   // GEMM_STAMP diagnostic build only (else null and unused)
+  int bm_cap;                   // host only: largest tile height the launch may use (0 = no cap)
   int xcd_split;                // split-K launches: all tiles of one K slice on one XCD (see the kernel's index mapping)
   const void* dref; int dact;   // epilogue: multiply by act'(dref[m][n]) (fused activation backward)
   float* colsum;                // epilogue: per-row-block column sums of the stored output, [tile_m][N]
@@ -49,23 +55,57 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define DMA_OOB 0x80000000u   // >= num_records of every descriptor built here: the DMA writes zeros
-#ifndef GEMM_STAGES
-#define GEMM_STAGES 3         // LDS buffers of the DMA pipeline (STAGES-1 K steps in flight)
+// K bytes per operand row per step (KB) and LDS ring depth are template parameters of the kernel; defaults per tile class
+// (the -D overrides exist for A/B builds only):
+//   4-wave tiles (<=128x128, 2-3 workgroups per CU): KB 128 (one full cache line per row and DMA piece), 2 stages
+//   256x128 persistent (8 waves, one workgroup per CU): KB 128, 3 stages (96 KB in flight) + 16 KB epilogue slab = 160 KB
+//   256x256 persistent (8 waves, one workgroup per CU): KB 64,  4 stages (96 KB in flight) + 32 KB epilogue slab = 160 KB
+#ifndef GEMM_NP_KB
+#define GEMM_NP_KB 128
 #endif
-// GEMM_ABLATE (tools/gemm_ablate.py only, never defined in the product build; results are WRONG by construction):
-//   1 no DMA inside the K loop   2 no MFMA (fragments still read)   3 no fragment reads, no MFMA   4 no epilogue stores
-#ifndef GEMM_ABLATE
-#define GEMM_ABLATE 0
+#ifndef GEMM_NP_STAGES
+#define GEMM_NP_STAGES 2
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define KEEP_LIVE(x) asm volatile("" ::"v"(x))
-#else
-#define KEEP_LIVE(x) (void)(x)
+#ifndef GEMM_NP_W128
+#define GEMM_NP_W128 8      // waves of the multi-workgroup 128x128 tile
+#endif
+#ifndef GEMM_P128_KB
+#define GEMM_P128_KB 128
+#endif
+#ifndef GEMM_P128_STAGES
+#define GEMM_P128_STAGES 3
+#endif
+#ifndef GEMM_P256_KB
+#define GEMM_P256_KB 64
+#endif
+#ifndef GEMM_P256_STAGES
+#define GEMM_P256_STAGES 4
+#endif
+#define MSCPLAN_NP_KB GEMM_NP_KB
+#include "gemm_plan.h"
+
+// GEMM_STAMP: diagnostic build only (make stamp -> libmsc_hip_stamp.so, tools/gemm_stamps.py); never defined in the product
+// build.  Wave 0 of every workgroup records shader-clock stamps (s_memtime) into a debug buffer of its own that no other
+// code reads: [0] entry, [1] first data landed, [2] cycles spent in the per-step DMA wait + barrier (summed), [3] K-loop
+// cycles (summed over tiles), [4] epilogue cycles (summed), [5] exit, [6] tiles, [7] K steps.
+#ifdef GEMM_STAMP
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" int msc_debug_gemm_stamps(unsigned long long* host_out, int nwg) {
+  if (!g_stamp_buf) return MSC_ERR_BAD_ARG;
+  return hipMemcpy(host_out, g_stamp_buf, (size_t)nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
+#define STAMP_NOW() __builtin_amdgcn_s_memtime()
 #endif
 
 template <int MODE> struct mode_is_kmajor { static constexpr bool value = (MODE == OPM_DENSE_K || MODE == OPM_CONV_FWD || MODE == OPM_CONV_DGRAD); };
 
-__device__ __forceinline__ int lds_chunk_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// byte offset of 16-byte chunk c of row `row` in a k-major LDS image with KB-byte rows.  ds_read_b128 serves 16 lanes
+// per LDS cycle from one 256-byte bank row = two image rows: with the XOR below the 16 rows of every lane group land on 16
+// different 16-byte slots (rows r, r+1 share (r>>1) but sit in different halves of the bank row).
+template <int KB> __device__ __forceinline__ int lds_chunk_off(int row, int c) {
+  if constexpr (KB == 128) return row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+  else return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);     // 64-byte rows: four rows per bank row
+}
 // swizzle of the 16-byte chunk index inside an mn-major LDS row of ROWB bytes, keyed by the k row
 template <int ROWB> __device__ __forceinline__ int mn_swz(int krow) {
   return ROWB >= 256 ? ((krow & 3) << 2) : (((krow >> 1) & 1) << 2);
@@ -97,33 +137,42 @@ __device__ __forceinline__ void dgrad_row_to_pixel(const GemmParams& p, int row,
 // ------------------------------------------------------------------------------------------------
 // Operand loader.  DMA = true: LDS-DMA path (k-major any dtype; mn-major bf16).  DMA = false: registers + transposing
 // LDS write (mn-major fp32 only).
-template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
+template <typename T, int MODE, int ROWS, int NTHR, int KB> struct OperandLoader {
   static constexpr bool KM = mode_is_kmajor<MODE>::value;
   static constexpr bool DMA = KM || sizeof(T) == 2;
   static constexpr int VEC = 16 / sizeof(T);
-  static constexpr int KT = 64 / sizeof(T);
-  static constexpr int NCH = ROWS * 4 / NTHR;                  // 16-byte chunks per thread per K step
-  static constexpr int ROWB = KM ? 64 : ROWS * (int)sizeof(T); // LDS row bytes
+  static constexpr int KT = KB / sizeof(T);
+  static constexpr int NCH = ROWS * (KB / 16) / NTHR;          // 16-byte chunks per thread per K step
+  static constexpr int ROWB = KM ? KB : ROWS * (int)sizeof(T); // LDS row bytes
+  static_assert(NCH >= 1, "tile too small for the thread count");
   static constexpr int CPR = ROWB / 16;                        // chunks per LDS row (DMA) / per reduction row (REG)
   static constexpr int RPI = 1024 / ROWB;                      // LDS rows written by one DMA wave-instruction
 
+  // k-major operands: the logical chunk c a lane moves depends on the lane and (KB = 128) on the PARITY of the DMA
+  // instruction index only, so everything derived from c — the k offset, the filter tap of a conv gather — is kept once
+  // per parity (NPAR values) instead of once per chunk; rows outside the matrix are marked in off / boff (DMA_OOB).
+  static_assert(!KM || NCH == 1 || NCH % 2 == 0, "chunk parity = instruction parity needs an even chunk count");
+  static constexpr int NPAR = KM ? (NCH > 1 ? 2 : 1) : NCH;
   __amdgpu_buffer_rsrc_t rs;
   const T* base;
   long ld;
-  uint32_t off[NCH];   // dense modes: running byte offset
-  int kk[NCH];         // current k (reduction index) of the chunk
-  bool ok[NCH];        // row (k-major) or column (mn-major) inside the matrix
-  int a0[NCH], a1[NCH], a2[NCH];  // fwd/dgrad: hi0, wi0, kh ; wgrad: ho, wo, b
-  int a3[NCH], a4[NCH];           // fwd/dgrad: kw, cin     ; wgrad: kh, kw
-  uint32_t boff[NCH];             // batch base (elements, fwd/dgrad) or cin (wgrad)
+  uint32_t off[NCH];   // dense modes: running byte offset (DENSE_K: DMA_OOB when the row is outside the matrix)
+  int kk[NPAR];        // DENSE_K: k offset of the chunk inside a K step (per parity); mn-major: current k of the chunk
+  bool ok[KM ? 1 : NCH];          // mn-major: column inside the matrix
+  int a0[NCH], a1[NCH];           // fwd/dgrad: hi0, wi0 ; wgrad: ho, wo
+  int a2[NPAR], a3[NPAR], a4[NPAR];   // fwd: kh, kw, cin (per parity) ; dgrad: a4 = channel offset ; wgrad: b / kh / kw per chunk
+  uint32_t boff[NCH];             // batch base (elements, fwd/dgrad; DMA_OOB: row outside) or cin (wgrad)
 
   // (row-in-tile, logical chunk) this thread moves for slot i
   static __device__ __forceinline__ void slot(int i, int& r, int& c) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if constexpr (DMA) {
       const int j = wave * NCH + i;                 // DMA instruction index inside the tile
-      if constexpr (KM) {
-        r = 16 * j + (lane >> 2);
+      if constexpr (KM && KB == 128) {
+        r = 8 * j + (lane >> 3);                    // 8 rows x one 128-byte line per DMA instruction
+        c = (lane & 7) ^ ((r >> 1) & 7);
+      } else if constexpr (KM) {
+        r = 16 * j + (lane >> 2);                   // 16 rows x half a line
         c = (lane & 3) ^ ((r >> 2) & 3);
       } else {
         r = RPI * j + lane / CPR;                   // k row inside the K step
@@ -147,9 +196,8 @@ template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
       if constexpr (MODE == OPM_DENSE_K) {
         // seek-based: the K step's base index comes from the schedule (KStep), so a strided dgrad can skip taps
         const int row = row0 + r;
-        ok[i] = row < rows_total;
-        kk[i] = c * VEC;
-        off[i] = (uint32_t)(((long)(ok[i] ? row : 0) * ld + kk[i]) * (long)sizeof(T));
+        if (i < NPAR) kk[i] = c * VEC;
+        off[i] = row < rows_total ? (uint32_t)(((long)row * ld + c * VEC) * (long)sizeof(T)) : DMA_OOB;
       } else if constexpr (MODE == OPM_DENSE_MN) {
         const int col = row0 + c * VEC;
         ok[i] = col < rows_total;
@@ -157,28 +205,30 @@ template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
         off[i] = (uint32_t)(((long)kk[i] * ld + (ok[i] ? col : 0)) * (long)sizeof(T));
       } else if constexpr (MODE == OPM_CONV_FWD) {
         const int row = row0 + r;
-        ok[i] = row < rows_total;
-        const int rr = ok[i] ? row : 0;
+        const bool inside = row < rows_total;
+        const int rr = inside ? row : 0;
         const int wo = rr % p.cWo, t = rr / p.cWo;
         const int ho = t % p.cHo, bb = t / p.cHo;
         a0[i] = ho * p.cS - p.cP;
         a1[i] = wo * p.cS - p.cP;
-        boff[i] = (uint32_t)bb * (uint32_t)(p.cH * p.cW * p.cC);
-        const int k = k0 + c * VEC;
-        const int tap = k >> p.cLogC;
-        a4[i] = k & (p.cC - 1);
-        a2[i] = tap / p.cKW;
-        a3[i] = tap - a2[i] * p.cKW;
+        boff[i] = inside ? (uint32_t)bb * (uint32_t)(p.cH * p.cW * p.cC) : DMA_OOB;
+        if (i < NPAR) {
+          const int k = k0 + c * VEC;
+          const int tap = k >> p.cLogC;
+          a4[i] = k & (p.cC - 1);
+          a2[i] = tap / p.cKW;
+          a3[i] = tap - a2[i] * p.cKW;
+        }
       } else if constexpr (MODE == OPM_CONV_DGRAD) {
         // rows are INPUT pixels (b,h,w) of size cH x cW; gathered tensor is dy [cB,cHo,cWo,cC]
         const int row = row0 + r;
-        ok[i] = row < rows_total;
+        const bool inside = row < rows_total;
         int h, w, bb;
-        dgrad_row_to_pixel(p, ok[i] ? row : 0, bb, h, w);
+        dgrad_row_to_pixel(p, inside ? row : 0, bb, h, w);
         a0[i] = h + p.cP;
         a1[i] = w + p.cP;
-        boff[i] = (uint32_t)bb * (uint32_t)(p.cHo * p.cWo * p.cC);
-        a4[i] = c * VEC;      // channel offset inside the K step; (kh, kw, co0) come from the schedule
+        boff[i] = inside ? (uint32_t)bb * (uint32_t)(p.cHo * p.cWo * p.cC) : DMA_OOB;
+        if (i < NPAR) a4[i] = c * VEC;      // channel offset inside the K step; (kh, kw, co0) come from the schedule
       } else {  // OPM_CONV_WGRAD: columns n=(kh,kw,cin) fixed per thread, reduction over (b,ho,wo)
         const int col = row0 + c * VEC;
         ok[i] = col < rows_total;
@@ -197,29 +247,28 @@ template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
     }
   }
 
-  // byte offset of slot i's chunk for the current K step (DMA_OOB where the element is padding), then advance
+  // byte offset of slot i's chunk for the current K step (DMA_OOB where the element is padding).  mn-major operands also
+  // advance their per-chunk state here; k-major ones advance once per step in end_step().
   __device__ __forceinline__ uint32_t next_offset(const GemmParams& p, int klimit, int i, const KStep& ks) {
     uint32_t v = DMA_OOB;
+    constexpr int PM = NPAR - 1;      // parity mask of the chunk index (k-major)
     if constexpr (MODE == OPM_DENSE_K) {
-      if (ok[i] && ks.kbase + kk[i] < klimit) v = off[i] + (uint32_t)ks.kbase * (uint32_t)sizeof(T);
+      if (off[i] != DMA_OOB && ks.kbase + kk[i & PM] < klimit) v = off[i] + (uint32_t)ks.kbase * (uint32_t)sizeof(T);
     } else if constexpr (MODE == OPM_DENSE_MN) {
       if (ok[i] && kk[i] < klimit) v = off[i];
       off[i] += (uint32_t)(KT * ld * (long)sizeof(T));
       kk[i] += KT;
     } else if constexpr (MODE == OPM_CONV_FWD) {
-      const int hi = a0[i] + a2[i], wi = a1[i] + a3[i];
-      if (ok[i] && a2[i] < p.cKH && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
-        v = (boff[i] + ((uint32_t)(hi * p.cW + wi) << p.cLogC) + (uint32_t)a4[i]) * (uint32_t)sizeof(T);
-      const int cin = a4[i] + KT;
-      a3[i] += cin >> p.cLogC;
-      a4[i] = cin & (p.cC - 1);
-      while (a3[i] >= p.cKW) { a3[i] -= p.cKW; ++a2[i]; }
+      const int q = i & PM;
+      const int hi = a0[i] + a2[q], wi = a1[i] + a3[q];
+      if (boff[i] != DMA_OOB && a2[q] < p.cKH && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
+        v = (boff[i] + ((uint32_t)(hi * p.cW + wi) << p.cLogC) + (uint32_t)a4[q]) * (uint32_t)sizeof(T);
     } else if constexpr (MODE == OPM_CONV_DGRAD) {
       const int th = a0[i] - ks.kh, tw = a1[i] - ks.kw;
       const int sm = p.cS - 1;
       const int ho = th >> p.cLogS, wo = tw >> p.cLogS;
-      if (ok[i] && ks.kh < p.cKH && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && ho < p.cHo && wo < p.cWo)
-        v = (boff[i] + ((uint32_t)(ho * p.cWo + wo) << p.cLogC) + (uint32_t)(ks.co0 + a4[i])) * (uint32_t)sizeof(T);
+      if (boff[i] != DMA_OOB && ks.kh < p.cKH && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && ho < p.cHo && wo < p.cWo)
+        v = (boff[i] + ((uint32_t)(ho * p.cWo + wo) << p.cLogC) + (uint32_t)(ks.co0 + a4[i & PM])) * (uint32_t)sizeof(T);
     } else {
       const int hi = a0[i] * p.cS - p.cP + a3[i], wi = a1[i] * p.cS - p.cP + a4[i];
       if (ok[i] && kk[i] < klimit && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW)
@@ -235,14 +284,30 @@ template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
     return v;
   }
 
-  // DMA path: enqueue this thread's chunks of the current K step into `tile` (LDS) and advance
-  __device__ __forceinline__ void issue(const GemmParams& p, int klimit, char* tile, const KStep& ks) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // once per K step after every chunk's offset was taken: advance the per-parity filter-tap state (conv forward gather)
+  __device__ __forceinline__ void end_step(const GemmParams& p) {
+    if constexpr (MODE == OPM_CONV_FWD) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const uint32_t v = next_offset(p, klimit, i, ks);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (wave * NCH + i) * 1024), 16, v, 0, 0, 0);
+      for (int q = 0; q < NPAR; ++q) {
+        const int cin = a4[q] + KT;
+        a3[q] += cin >> p.cLogC;
+        a4[q] = cin & (p.cC - 1);
+        while (a3[q] >= p.cKW) { a3[q] -= p.cKW; ++a2[q]; }
+      }
     }
+  }
+
+  // DMA path: enqueue chunk i of the current K step into `tile` (LDS)
+  __device__ __forceinline__ void issue_one(const GemmParams& p, int klimit, char* tile, const KStep& ks, int i) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t v = next_offset(p, klimit, i, ks);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (wave * NCH + i) * 1024), 16, v, 0, 0, 0);
+  }
+  // ... all chunks of the step, then advance
+  __device__ __forceinline__ void issue(const GemmParams& p, int klimit, char* tile, const KStep& ks) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) issue_one(p, klimit, tile, ks, i);
+    end_step(p);
   }
 
   // register path (mn-major fp32): load now, transpose into LDS later
@@ -253,6 +318,7 @@ template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
       regs[i] = (v == DMA_OOB) ? make_uint4(0, 0, 0, 0)
                                : *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + v);
     }
+    end_step(p);
   }
   __device__ __forceinline__ void store(char* tile, const uint4 (&regs)[NCH]) const {
 #pragma unroll
@@ -264,254 +330,368 @@ template <typename T, int MODE, int ROWS, int NTHR> struct OperandLoader {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const int row = cc * VEC + j;
-        *reinterpret_cast<uint32_t*>(tile + lds_chunk_off(row, kb >> 4) + (kb & 15)) = w[j];
+        *reinterpret_cast<uint32_t*>(tile + lds_chunk_off<KB>(row, kb >> 4) + (kb & 15)) = w[j];
       }
     }
   }
 };
 
-// XCD-aware bijective remap of the linear workgroup id (8 XCDs, round-robin dispatch): ids that share an XCD get a
-// contiguous range of tiles, so the n-tiles of one activation row-block hit one L2.  Speed only, never correctness.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, l = bid >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
-}
-
 // ------------------------------------------------------------------------------------------------
-// EPX: extended epilogue (fused activation backward + column sums) — compiled only into the kernels that use it so the
-// common epilogue keeps its register budget.
-template <typename T, int AMODE, int BMODE, int BM, int BN, bool EPX = false>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm_kernel(const GemmParams p) {
-  constexpr int NTHR = BM == 256 ? 512 : 256;   // 8 waves (4x2) for the 256-row tile, 4 waves (2x2) otherwise
-  constexpr int KT = 64 / sizeof(T);
-  constexpr int NWM = BM == 256 ? 4 : 2;        // waves along M
-  constexpr int WM = BM / NWM, WN = BN / 2, MI = WM / 32, NI = WN / 32;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-  constexpr int EP_BYTES = 64 * BN * 4;     // epilogue slab: 64 rows x BN fp32
-  using LA = OperandLoader<T, AMODE, BM, NTHR>;
-  using LB = OperandLoader<T, BMODE, BN, NTHR>;
+// The kernel.  EPX: extended epilogue (fused activation backward + column sums) — compiled only into the kernels that use
+// it so the common epilogue keeps its register budget.
+// PERSIST (256-row tiles, bf16, both operands k-major, one 8-wave workgroup per CU): gridDim.x workgroups walk the tiles
+// w = blockIdx.x, += gridDim.x.  The DMA issue side runs NSTAGE-1 K steps AHEAD of the MFMA side and simply rolls over
+// into the next tile, so the first steps of tile t+1 are already landing in the ring while tile t's epilogue stores its
+// output (the epilogue has its own LDS slab behind the ring and uses raw s_barrier + lgkmcnt only, so nothing drains the
+// DMAs).  A lone workgroup per CU otherwise pays load latency + epilogue un-overlapped on every tile, which at this path's
+// short K (8-72 steps) costs more than the larger tile saves.
+// Wave roles in the persistent kernels: vmcnt counts a wave's loads AND stores in order, so a wave that both stores an
+// output tile and waits for the next tile's DMA would have to see its stores complete first (HBM latency) — the K loop of
+// tile t+1 would stall behind the store burst of tile t.  Therefore waves 0-3 are the LOADERS (they issue every LDS-DMA
+// piece, interleaved between their MFMA sub-steps, and are the only ones that wait on vmcnt) and waves 4-7 are the STORERS
+// (they run the slab -> global half of the epilogue; their stores drain in the background under the next K loop and are
+// never waited for).  All eight waves run the MFMAs.
+struct Sched { KStep ks; int nk, s_kw0, s_step; };
+
+// NTHR: 512 (8 waves) for the 256-row tiles and for the 128x128 tile of the k-major / dense kernels (wave tile 32x64: four
+// waves per SIMD at two workgroups per CU — measured 3 % faster over the path's shapes, 15-20 % on the weight gradients),
+// 256 (4 waves, 2x2) otherwise.
+template <typename T, int AMODE, int BMODE, int BM, int BN, bool EPX, int KB, int NSTAGE, bool PERSIST, int NTHR>
+__global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm_kernel(const GemmParams p) {
+  constexpr int KT = KB / sizeof(T);
+  constexpr int NWN = BN == 256 ? 4 : 2;        // waves along N: 256x256 -> 2x4 (wave tile 128x64), 256x128 -> 4x2, else 2x2
+  constexpr int NWM = (NTHR / 64) / NWN;        // waves along M
+  constexpr int WM = BM / NWM, WN = BN / NWN, MI = WM / 32, NI = WN / 32;
+  constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB;
+  constexpr int NLOAD = PERSIST ? 256 : NTHR;   // threads that issue the staging loads (persistent: waves 0-3)
+  constexpr int NSTORE = PERSIST ? 256 : NTHR;  // threads that move the slab to global memory (persistent: waves 4-7)
+  using LA = OperandLoader<T, AMODE, BM, NLOAD, KB>;
+  using LB = OperandLoader<T, BMODE, BN, NLOAD, KB>;
+  static_assert(!PERSIST || (LA::DMA && LB::DMA), "the persistent pipeline is DMA-only");
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int STAGES = (LA::DMA && LB::DMA) ? GEMM_STAGES : 2;
-  constexpr int SMEM_BYTES = STAGES * STAGE_BYTES > EP_BYTES ? STAGES * STAGE_BYTES : EP_BYTES;
+  constexpr int STAGES = (LA::DMA && LB::DMA) ? NSTAGE : 2;
+  constexpr int SLAB_ROWS = PERSIST ? 32 : 64;          // output rows per epilogue pass through the fp32 slab
+  constexpr int EP_BYTES = SLAB_ROWS * BN * 4;
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES;
+  // non-persistent: the slab aliases the ring (the K loop is over); persistent: it sits behind the ring (DMAs in flight)
+  constexpr int SMEM_BYTES = PERSIST ? RING_BYTES + EP_BYTES : (RING_BYTES > EP_BYTES ? RING_BYTES : EP_BYTES);
+  static_assert(SMEM_BYTES <= 163840, "LDS budget of a CU");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
+  char* const ep_mem = PERSIST ? smem + RING_BYTES : smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const bool is_loader = !PERSIST || __builtin_amdgcn_readfirstlane(wave) < 4;
+  const bool is_storer = !PERSIST || !is_loader;
+  const int stid = PERSIST ? tid - 256 : tid;     // index among the storing threads
   const int ntn = (p.N + BN - 1) / BN;
-  // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest, then z).  Plain launches: tiles sharing an
-  // activation row block on one XCD (xcd_remap).  Split-K launches with nsplit % 8 == 0 (weight gradients): ALL tiles of
-  // one K slice on one XCD — they stream the same rows of both operands at the same time, so the slice is fetched into
-  // that L2 once instead of once per tile (PMC: weight-gradient HBM/fabric traffic was ~4x the algorithmic bytes).
-  int bid, zz, split;
-  if (p.xcd_split) {
-    const int L = blockIdx.z * gridDim.x + blockIdx.x;
-    const int q = L >> 3;
-    split = (L & 7) + 8 * (q / (int)gridDim.x);
-    bid = q % (int)gridDim.x;
-    zz = 0;
-  } else {
-    bid = xcd_remap(blockIdx.x, gridDim.x);
-    zz = blockIdx.z / p.nsplit;
-    split = blockIdx.z % p.nsplit;
-  }
-  const int tile_m = bid / ntn, tile_n = bid % ntn;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int zo = zz / p.batch_inner, zi = zz % p.batch_inner;
-
-  const T* Ab = reinterpret_cast<const T*>(p.A) + zo * p.sa_o + zi * p.sa_i;
-  const T* Bb = reinterpret_cast<const T*>(p.B) + zo * p.sb_o + zi * p.sb_i;
-
+  const int ntiles = ((p.M + BM - 1) / BM) * ntn;       // persistent mode: work items (host guarantees z == 1, no K split)
   const int nk_total = (p.K + KT - 1) / KT;
-  const int kt_begin = split * p.tiles_per_split;
-  const int kt_end = min(nk_total, kt_begin + p.tiles_per_split);
 
-  // ---- K schedule (wave-uniform).  Default: steps kt_begin..kt_end-1, kbase = kt*KT.  Strided dgrad whose tile lies
-  // inside one parity class: only the taps that class can see, (kh0, kh0+S, ..) x (kw0, kw0+S, ..).
-  KStep ks = {kt_begin * KT, 0, 0, 0};
-  int nk = kt_end - kt_begin;
-  int s_kw0 = 0, s_step = 1;
-  if constexpr (AMODE == OPM_CONV_DGRAD) {
-    int kh0 = 0;
-    if (p.cls) {
-      const int last = min(m0 + BM, p.M) - 1;
-      const int c0 = m0 / p.cMc;
-      if (c0 == last / p.cMc) {
-        kh0 = (c0 / p.cS + p.cP) % p.cS;
-        s_kw0 = (c0 % p.cS + p.cP) % p.cS;
-        s_step = p.cS;
-      }
-    }
-    const int cnt_h = kh0 < p.cKH ? (p.cKH - kh0 + s_step - 1) / s_step : 0;
-    const int cnt_w = s_kw0 < p.cKW ? (p.cKW - s_kw0 + s_step - 1) / s_step : 0;
-    nk = cnt_h * cnt_w * (p.cC / KT);
-    ks.kh = kh0;
-    ks.kw = s_kw0;
-    ks.kbase = (kh0 * p.cKW + s_kw0) << p.cLogC;
-    if (p.nsplit > 1) {   // split-K dgrad (the host only splits the plain (b,h,w) order): this slice starts mid-schedule
-      const int e = kt_begin * KT, tap = e >> p.cLogC;
-      ks.co0 = e & (p.cC - 1);
-      ks.kh = tap / p.cKW;
-      ks.kw = tap - ks.kh * p.cKW;
-      ks.kbase = e;
-      nk = kt_end - kt_begin;
-    }
-  }
-  auto advance = [&]() {
-    if constexpr (AMODE == OPM_CONV_DGRAD) {
-      ks.co0 += KT;
-      if (ks.co0 >= p.cC) {
-        ks.co0 = 0;
-        ks.kw += s_step;
-        if (ks.kw >= p.cKW) { ks.kw = s_kw0; ks.kh += s_step; }
-      }
-      ks.kbase = ((ks.kh * p.cKW + ks.kw) << p.cLogC) + ks.co0;
+  // ---- work item -> tile.  Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest, then z).  Plain
+  // launches: tiles sharing an activation row block on one XCD (xcd_remap).  Split-K launches with nsplit % 8 == 0 (weight
+  // gradients): ALL tiles of one K slice on one XCD — they stream the same rows of both operands at the same time, so the
+  // slice is fetched into that L2 once instead of once per tile (PMC: weight-gradient traffic was ~4x the algorithmic bytes).
+  // Persistent: item w runs on workgroup w % gridDim.x, and gridDim.x % 8 == 0 keeps w % 8 = the XCD group, so the same
+  // remap applies to the item index.
+  struct Geo { int tile_m, tile_n, m0, n0, split, zo, zi; };
+  auto decode = [&](int w, Geo& g) {
+    int bid, zz;
+    if constexpr (PERSIST) {
+      bid = mscplan::xcd_remap(w, ntiles);
+      zz = 0;
+      g.split = 0;
     } else {
-      ks.kbase += KT;
+      if (p.xcd_split) {
+        mscplan::xcd_split_map(blockIdx.z * gridDim.x + blockIdx.x, (int)gridDim.x, g.split, bid);
+        zz = 0;
+      } else {
+        bid = mscplan::xcd_remap(blockIdx.x, gridDim.x);
+        zz = blockIdx.z / p.nsplit;
+        g.split = blockIdx.z % p.nsplit;
+      }
+    }
+    g.tile_m = bid / ntn; g.tile_n = bid % ntn;
+    g.m0 = g.tile_m * BM; g.n0 = g.tile_n * BN;
+    g.zo = zz / p.batch_inner; g.zi = zz % p.batch_inner;
+  };
+
+  // ---- K schedule of one tile (wave-uniform).  Default: steps kt_begin..kt_end-1, kbase = kt*KT.  Strided dgrad whose tile
+  // lies inside one parity class: only the taps that class can see, (kh0, kh0+S, ..) x (kw0, kw0+S, ..).  Returns kt_begin.
+  auto sched_setup = [&](int tm0, int tsplit, Sched& sc) -> int {
+    const int kt_begin = tsplit * p.tiles_per_split;
+    const int kt_end = min(nk_total, kt_begin + p.tiles_per_split);
+    sc.ks = {kt_begin * KT, 0, 0, 0};
+    sc.nk = kt_end - kt_begin;
+    sc.s_kw0 = 0;
+    sc.s_step = 1;
+    if constexpr (AMODE == OPM_CONV_DGRAD) {
+      int kh0 = 0;
+      if (p.cls) {
+        const int last = min(tm0 + BM, p.M) - 1;
+        const int c0 = tm0 / p.cMc;
+        if (c0 == last / p.cMc) {
+          kh0 = (c0 / p.cS + p.cP) % p.cS;
+          sc.s_kw0 = (c0 % p.cS + p.cP) % p.cS;
+          sc.s_step = p.cS;
+        }
+      }
+      const int cnt_h = kh0 < p.cKH ? (p.cKH - kh0 + sc.s_step - 1) / sc.s_step : 0;
+      const int cnt_w = sc.s_kw0 < p.cKW ? (p.cKW - sc.s_kw0 + sc.s_step - 1) / sc.s_step : 0;
+      sc.nk = cnt_h * cnt_w * (p.cC / KT);
+      sc.ks.kh = kh0;
+      sc.ks.kw = sc.s_kw0;
+      sc.ks.kbase = (kh0 * p.cKW + sc.s_kw0) << p.cLogC;
+      if (p.nsplit > 1) {   // split-K dgrad (the host only splits the plain (b,h,w) order): this slice starts mid-schedule
+        const int e = kt_begin * KT, tap = e >> p.cLogC;
+        sc.ks.co0 = e & (p.cC - 1);
+        sc.ks.kh = tap / p.cKW;
+        sc.ks.kw = tap - sc.ks.kh * p.cKW;
+        sc.ks.kbase = e;
+        sc.nk = kt_end - kt_begin;
+      }
+    }
+    return kt_begin;
+  };
+  auto advance = [&](Sched& sc) {
+    if constexpr (AMODE == OPM_CONV_DGRAD) {
+      sc.ks.co0 += KT;
+      if (sc.ks.co0 >= p.cC) {
+        sc.ks.co0 = 0;
+        sc.ks.kw += sc.s_step;
+        if (sc.ks.kw >= p.cKW) { sc.ks.kw = sc.s_kw0; sc.ks.kh += sc.s_step; }
+      }
+      sc.ks.kbase = ((sc.ks.kh * p.cKW + sc.ks.kw) << p.cLogC) + sc.ks.co0;
+    } else {
+      sc.ks.kbase += KT;
     }
   };
 
+  // ---- issue side: (tile iw, step ik of isc.nk) and the loaders positioned there
   LA la;
   LB lb;
-  la.init(p, Ab, p.lda, p.M, m0, kt_begin * KT);
-  lb.init(p, Bb, p.ldb, p.N, n0, kt_begin * KT);
-
-  f32x16_t acc[MI][NI];
+  Sched isc;
+  int iw = PERSIST ? (int)blockIdx.x : 0, ik = 0;
+  auto issue_begin_tile = [&](int w) {
+    Geo g;
+    decode(w, g);
+    const int kt_begin = sched_setup(g.m0, g.split, isc);
+    if (is_loader) {
+      const T* Ab = reinterpret_cast<const T*>(p.A) + g.zo * p.sa_o + g.zi * p.sa_i;
+      const T* Bb = reinterpret_cast<const T*>(p.B) + g.zo * p.sb_o + g.zi * p.sb_i;
+      la.init(p, Ab, p.lda, p.M, g.m0, kt_begin * KT);
+      lb.init(p, Bb, p.ldb, p.N, g.n0, kt_begin * KT);
+    }
+    ik = 0;
+  };
+  int islot = 0, cslot = 0, inflight = 0;   // ring slot of the next issue / next compute; K steps issued and not yet consumed
+  // A K step goes into the ring in three parts so the loaders can spread the DMA pieces between their MFMA sub-steps:
+  // issue_open (pick the step, rolling over into this workgroup's next tile in persistent mode; false: nothing left),
+  // issue_pieces<lo,hi> (pieces lo..hi-1 of the NPS = A chunks then B chunks), issue_close (advance the schedule).
+  constexpr int NPS = LA::NCH + LB::NCH;              // staging instructions per K step and loading wave
+  auto issue_open = [&]() -> bool {
+    while (ik == isc.nk) {
+      if constexpr (!PERSIST) return false;
+      iw += (int)gridDim.x;
+      if (iw >= ntiles) { ik = isc.nk = 0; iw = ntiles; return false; }
+      issue_begin_tile(iw);
+    }
+    return true;
+  };
+  auto issue_pieces = [&](auto lo_c, auto hi_c) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    if (!is_loader) return;
+    char* buf = smem + islot * STAGE_BYTES;
+    if constexpr (LA::DMA && LB::DMA) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  uint4 ra[LA::NCH], rb[LB::NCH];
+      for (int i = LO; i < HI; ++i) {
+        if (i < LA::NCH) la.issue_one(p, p.K, buf, isc.ks, i);
+        else lb.issue_one(p, p.K, buf + A_BYTES, isc.ks, i - LA::NCH);
+      }
+    } else if constexpr (LO == 0) {   // register path (fp32 mn-major operands, parity mode): everything in the first part
+      if constexpr (LA::DMA) la.issue(p, p.K, buf, isc.ks);
+      else { uint4 ra[LA::NCH]; la.load(p, p.K, ra, isc.ks); la.store(buf, ra); }
+      if constexpr (LB::DMA) lb.issue(p, p.K, buf + A_BYTES, isc.ks);
+      else { uint4 rb[LB::NCH]; lb.load(p, p.K, rb, isc.ks); lb.store(buf + A_BYTES, rb); }
+    }
+  };
+  auto issue_close = [&]() {
+    if constexpr (LA::DMA && LB::DMA) {
+      if (is_loader) { la.end_step(p); lb.end_step(p); }
+    }
+    advance(isc);
+    ++ik;
+    ++inflight;
+    islot = islot + 1 == STAGES ? 0 : islot + 1;
+  };
+  auto issue_step = [&]() {     // whole step at once (prologue)
+    if (!issue_open()) return;
+    issue_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, NPS>{});
+    issue_close();
+  };
 
   // Software pipeline: STAGES LDS buffers, STAGES-1 K steps of LDS-DMA in flight.  Every wave waits for its own DMA
   // instructions of the step it is about to read with a COUNTED vmcnt (the younger steps stay in flight across the
   // barrier), then a raw s_barrier makes every wave's part visible (cdna_hip_programming.md "Pipelining across barriers").
-  constexpr int NPS = LA::NCH + LB::NCH;              // DMA wave-instructions per K step
   constexpr int WAIT_N = NPS * (STAGES - 2);          // instructions of the younger in-flight steps
-  int issued = 0;
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) {
-    if (issued < nk) {
-      char* buf = smem + s * STAGE_BYTES;
-      if constexpr (LA::DMA) la.issue(p, p.K, buf, ks); else { la.load(p, p.K, ra, ks); la.store(buf, ra); }
-      if constexpr (LB::DMA) lb.issue(p, p.K, buf + A_BYTES, ks); else { lb.load(p, p.K, rb, ks); lb.store(buf + A_BYTES, rb); }
-      advance();
-      ++issued;
+  // the OLDEST outstanding step must have landed; the inflight-1 younger ones may stay in flight when the pipe is full
+  // (the epilogue's global stores count in vmcnt too: they only make this wait conservative, never early)
+  auto wait_oldest = [&]() {
+    if (is_loader) {
+      if (STAGES > 2 && inflight - 1 == STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_N) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  }
-  if (issued == STAGES - 1 && STAGES > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_N) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  const int lr = lane & 31, lh = lane >> 5;
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = issued < nk;
-    int nb = cur + (STAGES - 1);
-    if (nb >= STAGES) nb -= STAGES;
-    char* nxt = smem + nb * STAGE_BYTES;
-    if (more) {
-      if constexpr (GEMM_ABLATE != 1) {
-        if constexpr (LA::DMA) la.issue(p, p.K, nxt, ks); else la.load(p, p.K, ra, ks);
-        if constexpr (LB::DMA) lb.issue(p, p.K, nxt + A_BYTES, ks); else lb.load(p, p.K, rb, ks);
-      }
-      advance();
-      ++issued;
-    }
-    const char* As = smem + cur * STAGE_BYTES;
-    const char* Bs = As + A_BYTES;
-    if constexpr (GEMM_ABLATE == 3) {
-    } else if constexpr (sizeof(T) == 2) {
-      // lane geometry of the transposed read (mn-major images): 16-lane group g, row q / column quad pq inside it
-      const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        mfma_bf16x8_t fa[MI], fb[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if constexpr (LA::KM) {
-            fa[i] = *reinterpret_cast<const mfma_bf16x8_t*>(As + lds_chunk_off(wm * WM + i * 32 + lr, 2 * ks + lh));
-          } else {
-            const int col = wm * WM + i * 32 + 16 * (tg & 1) + 4 * tp;
-            const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
-            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                As + k0r * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r)) << 4) + (tp & 1) * 8));
-            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                As + (k0r + 4) * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
-            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-            s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            fa[i] = __builtin_bit_cast(mfma_bf16x8_t, v);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          if constexpr (LB::KM) {
-            fb[j] = *reinterpret_cast<const mfma_bf16x8_t*>(Bs + lds_chunk_off(wn * WN + j * 32 + lr, 2 * ks + lh));
-          } else {
-            const int col = wn * WN + j * 32 + 16 * (tg & 1) + 4 * tp;
-            const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
-            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                Bs + k0r * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r)) << 4) + (tp & 1) * 8));
-            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                Bs + (k0r + 4) * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
-            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-            s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            fb[j] = __builtin_bit_cast(mfma_bf16x8_t, v);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            if constexpr (GEMM_ABLATE == 2) { KEEP_LIVE(fa[i]); KEEP_LIVE(fb[j]); }
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int k = 2 * ks + lh;  // float index inside the 16-float row
-        float fa[MI], fb[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          fa[i] = *reinterpret_cast<const float*>(As + lds_chunk_off(wm * WM + i * 32 + lr, k >> 2) + (k & 3) * 4);
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          fb[j] = *reinterpret_cast<const float*>(Bs + lds_chunk_off(wn * WN + j * 32 + lr, k >> 2) + (k & 3) * 4);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    if (more) {
-      if constexpr (!LA::DMA) la.store(nxt, ra);
-      if constexpr (!LB::DMA) lb.store(nxt + A_BYTES, rb);
-    }
-    // step kt+1 must have landed (this wave's part); steps kt+2.. may stay in flight when the pipe is full
-    if (STAGES > 2 && issued - (kt + 2) == STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads of this buffer are done before it is refilled
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads (and register-path writes) are done
     __builtin_amdgcn_s_barrier();                        // ... and every other wave's DMA part is visible
     asm volatile("" ::: "memory");                       // keep the next step's LDS traffic below the barrier
-    cur = cur + 1 == STAGES ? 0 : cur + 1;
-  }
-  __syncthreads();
-  if constexpr (GEMM_ABLATE == 4) {   // keep the accumulators live, store nothing
+  };
+
+#ifdef GEMM_STAMP
+  unsigned long long st_entry = STAMP_NOW(), st_wait = 0, st_k = 0, st_ep = 0, st_first, st_tiles = 0, st_steps = 0;
+#endif
+  issue_begin_tile(iw);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue_step();
+  wait_oldest();
+#ifdef GEMM_STAMP
+  st_first = STAMP_NOW();
+#endif
+
+  const int lr = lane & 31, lh = lane >> 5;
+  for (int w = PERSIST ? (int)blockIdx.x : 0; PERSIST ? (w < ntiles) : (w == 0); w += PERSIST ? (int)gridDim.x : 1) {
+    Sched csc;
+    Geo cg;
+    decode(w, cg);
+    const int tile_m = cg.tile_m, m0 = cg.m0, n0 = cg.n0, split = cg.split, zo = cg.zo, zi = cg.zi;
+    sched_setup(m0, split, csc);
+    const int nk = csc.nk;
+
+    f32x16_t acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) KEEP_LIVE(acc[i][j]);
-    if (p.M > 0) return;
-  }
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#ifdef GEMM_STAMP
+    const unsigned long long st_k0 = STAMP_NOW();
+    st_tiles += 1; st_steps += nk;
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = issue_open();
+      constexpr int NKS = sizeof(T) == 2 ? KT / 16 : 1;     // MFMA sub-steps the DMA pieces are spread over (bf16)
+#ifndef GEMM_INTERLEAVE_NP
+#define GEMM_INTERLEAVE_NP 0     // measured: spreading the pieces costs the multi-workgroup kernels 10-30 % (the DMA starts later)
+#endif
+      // DMA pieces spread between the MFMA sub-steps (bf16 DMA kernels) or issued up front (register path / fp32)
+      constexpr bool SPREAD = sizeof(T) == 2 && LA::DMA && LB::DMA && (PERSIST || GEMM_INTERLEAVE_NP);
+      if constexpr (!SPREAD) {
+        if (more) issue_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, NPS>{});
+      }
+      const char* As = smem + cslot * STAGE_BYTES;
+      const char* Bs = As + A_BYTES;
+      if constexpr (sizeof(T) == 2) {
+        // lane geometry of the transposed read (mn-major images): 16-lane group g, row q / column quad pq inside it
+        const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {
+          mfma_bf16x8_t fa[MI], fb[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            if constexpr (LA::KM) {
+              fa[i] = *reinterpret_cast<const mfma_bf16x8_t*>(As + lds_chunk_off<KB>(wm * WM + i * 32 + lr, 2 * ks + lh));
+            } else {
+              const int col = wm * WM + i * 32 + 16 * (tg & 1) + 4 * tp;
+              const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
+              s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                  As + k0r * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r)) << 4) + (tp & 1) * 8));
+              s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                  As + (k0r + 4) * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
+              typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+              s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              fa[i] = __builtin_bit_cast(mfma_bf16x8_t, v);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            if constexpr (LB::KM) {
+              fb[j] = *reinterpret_cast<const mfma_bf16x8_t*>(Bs + lds_chunk_off<KB>(wn * WN + j * 32 + lr, 2 * ks + lh));
+            } else {
+              const int col = wn * WN + j * 32 + 16 * (tg & 1) + 4 * tp;
+              const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
+              s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                  Bs + k0r * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r)) << 4) + (tp & 1) * 8));
+              s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                  Bs + (k0r + 4) * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
+              typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+              s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              fb[j] = __builtin_bit_cast(mfma_bf16x8_t, v);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          if constexpr (SPREAD) {      // this sub-step's share of the next step's DMA pieces, behind its MFMAs
+            if (more) {
+              if (ks == 0) issue_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, NPS * 1 / NKS>{});
+              if constexpr (NKS > 1) { if (ks == 1) issue_pieces(std::integral_constant<int, NPS * 1 / NKS>{}, std::integral_constant<int, NPS * 2 / NKS>{}); }
+              if constexpr (NKS > 2) { if (ks == 2) issue_pieces(std::integral_constant<int, NPS * 2 / NKS>{}, std::integral_constant<int, NPS * 3 / NKS>{}); }
+              if constexpr (NKS > 3) { if (ks == 3) issue_pieces(std::integral_constant<int, NPS * 3 / NKS>{}, std::integral_constant<int, NPS>{}); }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KT / 2; ++ks) {
+          const int k = 2 * ks + lh;  // float index inside the row
+          float fa[MI], fb[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            fa[i] = *reinterpret_cast<const float*>(As + lds_chunk_off<KB>(wm * WM + i * 32 + lr, k >> 2) + (k & 3) * 4);
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            fb[j] = *reinterpret_cast<const float*>(Bs + lds_chunk_off<KB>(wn * WN + j * 32 + lr, k >> 2) + (k & 3) * 4);
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (more) issue_close();
+      cslot = cslot + 1 == STAGES ? 0 : cslot + 1;
+      --inflight;
+#ifdef GEMM_STAMP
+      const unsigned long long st_w0 = STAMP_NOW();
+      wait_oldest();
+      st_wait += STAMP_NOW() - st_w0;
+#else
+      wait_oldest();
+#endif
+    }
+#ifdef GEMM_STAMP
+    const unsigned long long st_k1 = STAMP_NOW();
+    st_k += st_k1 - st_k0;
+#endif
+    if constexpr (!PERSIST) __syncthreads();   // the slab aliases the ring
+
+#define EP_SYNC()                                                                                   \
+  do {                                                                                              \
+    if constexpr (PERSIST) {                                                                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+      __builtin_amdgcn_s_barrier();                                                                 \
+      asm volatile("" ::: "memory");                                                                \
+    } else {                                                                                        \
+      __syncthreads();                                                                              \
+    }                                                                                               \
+  } while (0)
 
   // ---------------------------------------------------------------- epilogue
   // (1) BatchNorm partial statistics straight from the fp32 accumulators (conv forward only)
   if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [NWM][2 stat][BN]
+    float* red = reinterpret_cast<float*>(ep_mem);  // [NWM][2 stat][BN]
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       float s1 = 0.f, s2 = 0.f;
@@ -527,49 +707,50 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
         red[(wm * 2 + 1) * BN + wn * WN + j * 32 + lr] = s2;
       }
     }
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
+    EP_SYNC();
+    if (is_storer && stid < BN && n0 + stid < p.N) {
       float* st = p.stats + (long)tile_m * 2 * p.N;
       float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < NWM; ++w) { a1 += red[(w * 2 + 0) * BN + tid]; a2 += red[(w * 2 + 1) * BN + tid]; }
-      st[n0 + tid] = a1;
-      st[p.N + n0 + tid] = a2;
+      for (int w = 0; w < NWM; ++w) { a1 += red[(w * 2 + 0) * BN + stid]; a2 += red[(w * 2 + 1) * BN + stid]; }
+      st[n0 + stid] = a1;
+      st[p.N + n0 + stid] = a2;
     }
-    __syncthreads();
+    EP_SYNC();
   }
 
-  // (2) accumulators -> LDS slab (fp32, 64 rows per pass) -> 16-byte coalesced global stores with the fused
+  // (2) accumulators -> LDS slab (fp32, SLAB_ROWS rows per pass) -> 16-byte coalesced global stores with the fused
   //     bias / pre-activation copy / activation / residual applied on whole vectors
-  float* slab = reinterpret_cast<float*>(smem);
+  float* slab = reinterpret_cast<float*>(ep_mem);
   const bool f32out = (p.nsplit > 1 || p.out_f32);
   char* Cbase = f32out ? reinterpret_cast<char*>(reinterpret_cast<float*>(p.C) + (p.nsplit > 1 ? (long)split * p.M * p.ldc : (zo * p.sc_o + zi * p.sc_i)))
                        : reinterpret_cast<char*>(reinterpret_cast<T*>(p.C) + zo * p.sc_o + zi * p.sc_i);
-  constexpr int PASSES = BM / 64;
-  float csum[16 / sizeof(T)];   // this thread's column chunk is the same in every iteration (NTHR % (BN/VEC) == 0)
+  constexpr int PASSES = BM > SLAB_ROWS ? BM / SLAB_ROWS : 1;   // SLAB_ROWS output rows per pass (BM = 64: the whole tile)
+  float csum[16 / sizeof(T)];   // this thread's column chunk is the same in every iteration (NSTORE % (BN/VEC) == 0)
 #pragma unroll
   for (int e = 0; e < (int)(16 / sizeof(T)); ++e) csum[e] = 0.f;
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
-    const bool mine = (PASSES == 1) || (wm == ps);
-    if (mine) {
-      const int rbase = (PASSES == 1) ? wm * WM : 0;
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+      const int r0 = wm * WM + i * 32;            // first tile row of this 32-row accumulator block (wave-uniform)
+      if (r0 / SLAB_ROWS != ps) continue;         // not in this pass's rows
+      const int rbase = r0 - ps * SLAB_ROWS;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            slab[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WN + j * 32 + lr] = p.alpha * acc[i][j][r];
+        for (int r = 0; r < 16; ++r)
+          slab[(rbase + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WN + j * 32 + lr] = p.alpha * acc[i][j][r];
     }
-    __syncthreads();
-    if (f32out) {
+    EP_SYNC();
+    if (!is_storer) {
+    } else if (f32out) {
       constexpr int CPRW = BN / 4;
 #pragma unroll
-      for (int it = 0; it < 64 * CPRW / NTHR; ++it) {
-        const int id = tid + it * NTHR;
+      for (int it = 0; it < SLAB_ROWS * CPRW / NSTORE; ++it) {
+        const int id = stid + it * NSTORE;
         const int row = id / CPRW, cc = id % CPRW;
-        const int m = m0 + ps * 64 + row, n = n0 + cc * 4;
+        const int m = m0 + ps * SLAB_ROWS + row, n = n0 + cc * 4;
         if (m >= p.M || n >= p.N) continue;
         const float4 v = *reinterpret_cast<const float4*>(slab + row * BN + cc * 4);
         float* dst = reinterpret_cast<float*>(Cbase) + (long)m * p.ldc + n;
@@ -586,10 +767,10 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
       T* C2 = reinterpret_cast<T*>(p.C2);
       const T* Rs = reinterpret_cast<const T*>(p.res);
 #pragma unroll
-      for (int it = 0; it < 64 * CPRW / NTHR; ++it) {
-        const int id = tid + it * NTHR;
+      for (int it = 0; it < SLAB_ROWS * CPRW / NSTORE; ++it) {
+        const int id = stid + it * NSTORE;
         const int row = id / CPRW, cc = id % CPRW;
-        const int m = m0 + ps * 64 + row, n = n0 + cc * VEC;
+        const int m = m0 + ps * SLAB_ROWS + row, n = n0 + cc * VEC;
         if (m >= p.M || n >= p.N) continue;
         float v[VEC];
 #pragma unroll
@@ -661,23 +842,38 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 4 : 2) void gemm
         }
       }
     }
-    if (ps + 1 < PASSES) __syncthreads();
+    if (ps + 1 < PASSES) EP_SYNC();
   }
   if (EPX && p.colsum && !f32out) {
     // fixed-order reduction of the per-thread column sums over the NTHR/(BN/VEC) threads that share a column chunk
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int CPRW = BN / VEC, NR = NTHR / CPRW;
-    __syncthreads();
-    const int cc = tid % CPRW, rr = tid / CPRW;
+    constexpr int CPRW = BN / VEC, NR = NSTORE / CPRW;
+    static_assert(NR <= SLAB_ROWS, "column-sum scratch must fit the slab");
+    EP_SYNC();
+    const int cc = stid % CPRW, rr = stid / CPRW;
+    if (is_storer) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) slab[rr * BN + cc * VEC + e] = csum[e];
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
+      for (int e = 0; e < VEC; ++e) slab[rr * BN + cc * VEC + e] = csum[e];
+    }
+    EP_SYNC();
+    if (is_storer && stid < BN && n0 + stid < p.N) {
       float a = 0.f;
-      for (int r = 0; r < NR; ++r) a += slab[r * BN + tid];
-      p.colsum[(long)tile_m * p.N + n0 + tid] = a;
+      for (int r = 0; r < NR; ++r) a += slab[r * BN + stid];
+      p.colsum[(long)tile_m * p.N + n0 + stid] = a;
     }
   }
+    if constexpr (PERSIST) EP_SYNC();   // the slab is free again before the next tile's epilogue touches it
+#ifdef GEMM_STAMP
+    st_ep += STAMP_NOW() - st_k1;
+#endif
+  }   // tile loop
+#ifdef GEMM_STAMP
+  if (p.stamps && tid == 0) {
+    unsigned long long* o = p.stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    o[0] = st_entry; o[1] = st_first; o[2] = st_wait; o[3] = st_k; o[4] = st_ep; o[5] = STAMP_NOW(); o[6] = st_tiles; o[7] = st_steps;
+  }
+#endif
+#undef EP_SYNC
 }
 
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i]   (fixed order: bitwise reproducible)
@@ -762,63 +958,68 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   }
 }
 
-// Split-K for chip-underfilling conv forward / stride-1 dgrad launches (the deep ResNet layers: 64 frames x 7x7 or 14x14
-// pixels give 100-200 tiles of 128x128 for 256 CUs, and 64-wide tiles run 4 MFMAs per barrier): 128x128 tiles over ns K
-// slices + the finish kernel above.  Returns 1 when the launch fills the chip or K is too short to split.
-static int plan_conv_split(long M, long N, long nk) {
-  const char* e = getenv("MSC_CONV_SPLITK");      // A/B + test knob, read per call so a test can switch it inside one process
-  const int on = e ? atoi(e) : 1;
-  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-  if (!on || tiles >= 200 || nk < 32 || N % 4) return 1;
-  long ns = (400 + tiles / 2) / tiles;     // ~400 workgroups (measured: layer3 best at 2 slices, layer4 at 4)
-  if (ns > 8) ns = 8;
-  while (ns > 1 && nk / ns < 16) --ns;
-  return (int)ns;
+// ---- launch planning lives in gemm_plan.h (plain C++, fuzzed under ASan/UBSan by tests/host_san)
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+// the persistent 256-row kernels exist for bf16 with both operands k-major (conv gathers count as k-major A)
+static inline bool can_persist(int amode, int bmode, int dtype) {
+  return dtype == MSC_BF16 && bmode == OPM_DENSE_K && (amode == OPM_DENSE_K || amode == OPM_CONV_FWD || amode == OPM_CONV_DGRAD);
+}
+// big = the launch may take the persistent 256x256 kernel: never for launches whose epilogue writes per-row-block side
+// buffers sized by a query (BatchNorm partials, column sums), so those queries depend on (rows, cols) only
+static inline mscplan::Tile tile_for(long M, long N, long zs, int amode, int bmode, int dtype, long K = 0, bool big = false, int bm_cap = 256) {
+  return mscplan::choose_tile(M, N, zs, big && can_persist(amode, bmode, dtype) && zs == 1, num_cus(), K, bm_cap);
 }
 
 extern "C" int64_t msc_conv2d_splitk_workspace_bytes(int64_t rows, int cout, int64_t k_len, int dtype) {
-  const int ns = plan_conv_split(rows, cout, cdiv(k_len, dtype == MSC_F32 ? 16 : 32));
-  return ns > 1 ? (int64_t)ns * rows * cout * 4 : 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// tile choice: narrow operands get 64-wide tiles; launches that would leave most of the 256 CUs idle trade MFMA work
-// per LDS byte for more workgroups
-static void choose_tile(long M, long N, long zs, int& bm, int& bn, bool allow256 = true) {
-  bm = M <= 64 ? 64 : 128;
-  bn = N <= 64 ? 64 : 128;
-  // Measured (tools/gemm_ceiling.py): the kernel runs at the same rate whether its operands stream from HBM or sit in
-  // cache — the bound is the per-CU LDS fill path (LDS-DMA, ~55 GB/s per CU), so FLOPs per staged byte is the lever:
-  // 256x128 tiles (8 waves) raise it from 64 to 85 and are used when they still fill the chip.  A 256x256 tile (128
-  // FLOP/B, one workgroup per CU) was built and measured: slower at this path's short K (16-72 steps), where the
-  // un-overlapped prologue/epilogue of a lone workgroup costs more than the fill it saves.
-  // 256-row tiles only for launches of >= 1000 of them: measured inside the three-stream step, 128x128 tiles co-schedule
-  // better with the side-stream weight gradients for everything smaller (step 9.07 -> 8.99 ms), although the 256-row
-  // tile wins some of those shapes when they run alone.
-  if (allow256 && bn == 128 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 128) * zs >= 1000) { bm = 256; return; }
-  // (threshold measured inside the step: 200 tiles; 320+ shrinks tiles that were better left at 128)
-  if (bn == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 200) bn = 64;
-  if (bm == 128 && (long)cdiv(M, bm) * cdiv(N, bn) * zs < 200) bm = 64;
+  return mscplan::conv_split(rows, cout, k_len, dtype == MSC_F32).ws_bytes;
 }
 
 // rows of the BatchNorm partial-statistics buffer msc_conv2d_fwd writes for an output of `rows` pixels x `cout`
-extern "C" int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout) {
-  int bm, bn;
-  choose_tile(rows, cout, 1, bm, bn);
-  return cdiv(rows, bm);
+extern "C" int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout, int dtype) {
+  return cdiv(rows, tile_for(rows, cout, 1, OPM_CONV_FWD, OPM_DENSE_K, dtype).bm);
 }
 
 template <typename T, int AMODE, int BMODE, bool EPX = false>
 static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
-  int bm, bn;
+  constexpr int DT = std::is_same<T, float>::value ? MSC_F32 : MSC_BF16;
   const long zs = (long)batch * p.nsplit;
-  choose_tile(p.M, p.N, zs, bm, bn, mode_is_kmajor<AMODE>::value && !EPX);   // 256-row tiles: k-major A, plain epilogue
+#ifdef GEMM_STAMP
+  if (!g_stamp_buf) (void)hipMalloc(&g_stamp_buf, (size_t)(1 << 20) * 8 * sizeof(unsigned long long));
+  const_cast<GemmParams&>(p).stamps = g_stamp_buf;
+#endif
+  const bool big = p.nsplit == 1 && !p.xcd_split && !p.stats && !p.colsum;
+  const mscplan::Tile t = tile_for(p.M, p.N, zs, AMODE, BMODE, DT, p.K, big, p.bm_cap ? p.bm_cap : 256);
+  const int bm = t.bm, bn = t.bn;
+  if (zs > 65535) return MSC_ERR_UNSUPPORTED;
+  if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
+    if (bm == 256) {     // persistent: one workgroup per CU walks the tiles
+      const int ntiles = cdiv(p.M, 256) * cdiv(p.N, bn);
+      const int ncu = num_cus();
+      dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu), 1, 1);
+      if (bn == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 256, EPX, GEMM_P256_KB, GEMM_P256_STAGES, true, 512>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, GEMM_P128_KB, GEMM_P128_STAGES, true, 512>), grid, dim3(512), 0, st, p);
+      return msc_launch_status();
+    }
+  }
+  if (bm > 128 || bn > 128) return MSC_ERR_UNSUPPORTED;
   dim3 grid((unsigned)(cdiv(p.M, bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
-  if (bm == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX>), grid, dim3(512), 0, st, p);
-  else if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX>), grid, dim3(256), 0, st, p);
-  else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64, EPX>), grid, dim3(256), 0, st, p);
-  else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128, EPX>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64, EPX>), grid, dim3(256), 0, st, p);
+  // K bytes per step / ring depth / waves of the multi-workgroup kernels (measured per operand mode, tools/gemm_sweep.py):
+  // gathered weight gradients (conv wgrad) run best on 64-byte steps x 3 stages x 4 waves (three workgroups per CU);
+  // everything else on 128-byte steps x 2 stages, the 128x128 tile with 8 waves
+  constexpr bool WG = BMODE == OPM_CONV_WGRAD;
+  constexpr int KBn = WG ? 64 : GEMM_NP_KB, S = WG ? 3 : GEMM_NP_STAGES, W128 = WG ? 256 : 64 * GEMM_NP_W128;
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX, KBn, S, false, W128>), grid, dim3(W128), 0, st, p);
+  else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, p);
+  else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64, EPX, KBn, S + 1, false, 256>), grid, dim3(256), 0, st, p);
   return msc_launch_status();
 }
 
@@ -840,54 +1041,24 @@ static GemmParams base_params() {
 }
 
 static inline int vec_of(int dtype) { return dtype == MSC_F32 ? 4 : 8; }
-static inline int kt_of(int dtype) { return dtype == MSC_F32 ? 16 : 32; }
+static inline int kt_of(int dtype) { return mscplan::kt_of_dtype(dtype == MSC_F32); }
 static inline int esize(int dtype) { return dtype == MSC_F32 ? 4 : 2; }
 // every operand is addressed with 32-bit byte offsets below DMA_OOB
 static inline bool fits32(long elems, int dtype) { return elems * esize(dtype) < 0x7ffffff0L; }
 
-// split-K plan shared by the workspace query and the launchers (independent of dtype)
-static int plan_split(long rows_out, long cols_out, long reduce_len) {
-  const long tiles = (long)cdiv(rows_out, 128) * cdiv(cols_out, cols_out <= 64 ? 64 : 128);
-  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~512 workgroups measured best
-  // (fewer: underfilled when the main stream idles; more: fp32 slab traffic = nsplit x output)
-  static long target = 0;
-  if (!target) {
-    const char* e = getenv("MSC_WGRAD_BLOCKS");   // tuning knob (A/B runs); default 512 (measured best of 128..1536)
-    target = e ? atol(e) : 512;
-    if (target < 1) target = 512;
-  }
-  long want = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
-  long cap = reduce_len / 1024;
-  if (want > cap) want = cap;
-  if (want < 1) want = 1;
-  if (want > 128) want = 128;
-  // multiples of 8 let the kernel pin each K slice to one XCD (xcd_split)
-  static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;   // A/B knob
-  if (xs && want >= 6) {
-    long w8 = (want + 4) / 8 * 8;
-    if (w8 > cap) w8 = cap / 8 * 8;
-    if (w8 >= 8) want = w8;
-  }
-  return (int)want;
-}
-
 extern "C" int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len) {
-  return (int64_t)plan_split(rows_out, cols_out, reduce_len) * rows_out * cols_out * 4;
+  return (int64_t)mscplan::plan_split(rows_out, cols_out, reduce_len) * rows_out * cols_out * 4;
 }
 
 static int finish_wgrad(GemmParams& p, float* dw, float* ws, int64_t ws_bytes, long reduce_len, int accumulate,
-                        int dtype, hipStream_t st, int (*launch)(const GemmParams&, int, int, hipStream_t)) {
-  const int KT = kt_of(dtype);
-  const int nk = cdiv(reduce_len, KT);
-  int ns = plan_split(p.M, p.N, reduce_len);
-  int tps = cdiv(nk, ns);
-  ns = cdiv(nk, tps);
+                        int dtype, hipStream_t st, int (*launch)(const GemmParams&, int, int, hipStream_t), int kstep_bytes) {
+  const mscplan::WgradSplit w = mscplan::wgrad_split(p.M, p.N, reduce_len, kstep_bytes / esize(dtype));
+  const int ns = w.ns;
   if ((int64_t)ns * p.M * p.N * 4 > ws_bytes || !ws) return MSC_ERR_BAD_ARG;
   if (((long)p.M * p.N) % 4) return MSC_ERR_BAD_ARG;
   p.nsplit = ns;
-  p.tiles_per_split = tps;
-  static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;
-  p.xcd_split = (xs && ns >= 8 && ns % 8 == 0) ? 1 : 0;
+  p.tiles_per_split = w.tps;
+  p.xcd_split = w.xcd_split;
   p.C = ws;
   p.ldc = p.N;
   p.out_f32 = 1;
@@ -921,12 +1092,11 @@ static int set_conv_geom(GemmParams& p, int B, int H, int W, int C, int Ho, int 
 template <int AMODE>
 static int launch_conv_maybe_split(GemmParams& p, void* out, const void* res, float* stats, float* ws, int64_t ws_bytes, int dtype,
                                    hipStream_t st) {
-  const int nk = cdiv(p.K, kt_of(dtype));
-  const int ns0 = (AMODE == OPM_CONV_DGRAD && p.cls) ? 1 : plan_conv_split(p.M, p.N, nk);
-  if (ns0 <= 1 || !ws || ws_bytes < (int64_t)ns0 * p.M * p.N * 4) return launch_gemm_dt<AMODE, OPM_DENSE_K>(p, 1, dtype, st);
-  const int tps = cdiv(nk, ns0), ns = cdiv(nk, tps);
-  int bm0, bn0;
-  choose_tile(p.M, p.N, 1, bm0, bn0);          // row granularity of the BatchNorm partials the caller sized its buffer for
+  mscplan::ConvSplit cs = mscplan::conv_split(p.M, p.N, p.K, dtype == MSC_F32);
+  if (AMODE == OPM_CONV_DGRAD && p.cls) cs.ns = 1;
+  if (cs.ns <= 1 || !ws || ws_bytes < (int64_t)cs.ns * p.M * p.N * 4) return launch_gemm_dt<AMODE, OPM_DENSE_K>(p, 1, dtype, st);
+  const int tps = cs.tps, ns = cs.ns;
+  const int bm0 = tile_for(p.M, p.N, 1, AMODE, OPM_DENSE_K, dtype).bm;   // row granularity of the BatchNorm partials the caller sized its buffer for
   p.nsplit = ns;
   p.tiles_per_split = tps;
   p.C = ws; p.ldc = p.N; p.out_f32 = 1;
@@ -976,6 +1146,10 @@ extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res,
     p.cH2 = H / stride;
     p.cW2 = W / stride;
     p.cMc = B * p.cH2 * p.cW2;
+    // a tile that straddles two parity classes iterates all taps instead of the 1/S^2 its class sees: keep the row tiles
+    // inside the classes when a 64-row tile does that and a 128-row one does not (layer 4 at 64 frames: 3136 rows per
+    // class — measured 67 -> 32 us)
+    if (p.cMc % 128 != 0 && p.cMc % 64 == 0) p.bm_cap = 64;
   }
   return launch_conv_maybe_split<OPM_CONV_DGRAD>(p, dx, res, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream);
 }
@@ -995,7 +1169,7 @@ extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.lda = Cout;
   if (set_conv_geom(p, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad) != MSC_OK) return MSC_ERR_BAD_ARG;
   return finish_wgrad(p, dw, ws, ws_bytes, p.K, accumulate, dtype, (hipStream_t)stream,
-                      launch_gemm_dt<OPM_DENSE_MN, OPM_CONV_WGRAD>);
+                      launch_gemm_dt<OPM_DENSE_MN, OPM_CONV_WGRAD>, 64);
 }
 
 extern "C" int msc_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, void* pre,
@@ -1011,10 +1185,8 @@ extern "C" int msc_linear_fwd(const void* x, const void* w, const float* bias, c
 }
 
 // rows of the column-sum partial buffer msc_linear_dgrad writes for an [M][K] output
-extern "C" int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K) {
-  int bm, bn;
-  choose_tile(M, K, 1, bm, bn, false);   // the extended-epilogue kernels never use the 256-row tile
-  return cdiv(M, bm);
+extern "C" int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K, int dtype) {
+  return cdiv(M, tile_for(M, K, 1, OPM_DENSE_K, OPM_DENSE_K, dtype).bm);
 }
 
 extern "C" int msc_linear_dgrad(const void* dy, const void* wt, const void* dact_ref, int dact, float* colsum_partial, void* dx, int M,
@@ -1040,7 +1212,7 @@ extern "C" int msc_linear_wgrad(const void* x, const void* dy, float* dw, float*
   p.A = dy; p.B = x;
   p.M = N; p.N = K; p.K = M; p.lda = N; p.ldb = K;
   return finish_wgrad(p, dw, ws, ws_bytes, M, accumulate, dtype, (hipStream_t)stream,
-                      launch_gemm_dt<OPM_DENSE_MN, OPM_DENSE_MN>);
+                      launch_gemm_dt<OPM_DENSE_MN, OPM_DENSE_MN>, GEMM_NP_KB);
 }
 
 extern "C" int msc_gemm_batched(const void* A, const void* Bm, void* C, int M, int N, int K, int64_t lda, int64_t ldb,

@@ -30,7 +30,7 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     M = B * Ho * Wo
-    nblk = L.query("msc_conv2d_fwd_stat_rows", M, Cout)
+    nblk = L.query("msc_conv2d_fwd_stat_rows", M, Cout, rt.dt)
     y_raw = rt.empty(B, Ho, Wo, Cout)
     partial = rt.workspace("bn_partial", nblk * 2 * Cout * 4)
     wsb = L.query("msc_conv2d_splitk_workspace_bytes", M, Cout, KH * KW * Cin, rt.dt)     # > 0: chip-underfilling launch -> split-K
@@ -196,7 +196,7 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
         dx = rt.empty(M, K)
         part = None
         if prev_bias is not None:
-            nblk = L.query("msc_linear_dgrad_colsum_rows", M, K)
+            nblk = L.query("msc_linear_dgrad_colsum_rows", M, K, rt.dt)
             part = rt.workspace("dgrad_colsum", nblk * K * 4)
         rt.call("msc_linear_dgrad", d, w.t, prev_ref, prev_act, part, dx, M, N, K, rt.dt)
         if prev_bias is not None:

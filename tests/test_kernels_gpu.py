@@ -134,7 +134,7 @@ def test_linear_dgrad_fused_act_and_bias(rts, dtype, M, N, K, act):
     (y @ q(w, dtype).t()).backward(q(dy, dtype))
     Wp = FakeParam(rt, w, "linear")
     dx = rt.empty(M, K)
-    nblk = L.query("msc_linear_dgrad_colsum_rows", M, K)
+    nblk = L.query("msc_linear_dgrad_colsum_rows", M, K, rt.dt)
     part = torch.full((nblk, K), float("nan"), device=rt.device)
     rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, dev(ref_in.detach(), rt), act, part, dx, M, N, K, rt.dt)
     check("dx", dx, pq.grad, tol(dtype) * 2)
@@ -177,6 +177,99 @@ def test_gemm_batched_layouts(rts, dtype):
             rt.call("msc_gemm_batched", Ad, Bd, C, M, N, K, lda, ldb, N, a_k, b_k, Bz, 2, 2 * Ad.shape[1] * Ad.shape[2],
                     Ad.shape[1] * Ad.shape[2], 2 * Bd.shape[1] * Bd.shape[2], Bd.shape[1] * Bd.shape[2], 2 * M * N, M * N, 0.5, 1, rt.dt)
             check(f"C a_k={a_k} b_k={b_k}", C, ref, tol(dtype, True))
+
+
+# ------------------------------------------------------------------------------------------------ persistent 256-row tiles
+PERSIST_TILES = ["256x128", "256x256"]
+
+
+@pytest.mark.parametrize("tile", PERSIST_TILES)
+@pytest.mark.parametrize("M,N,K,act,res", [(70000, 384, 192, 0, True),    # > 256 tiles: every workgroup walks several; ragged last row tile
+                                           (2100, 512, 64, 2, False),     # K = one step: the issue side rolls over tiles faster than the ring depth
+                                           (1024, 256, 2048, 3, True),    # long K, few tiles (fewer tiles than CUs)
+                                           (33000, 200, 328, 1, False)])  # N not a tile multiple, K not a step multiple
+def test_persistent_linear_fwd(rts, monkeypatch, tile, M, N, K, act, res):
+    """the persistent kernels (one workgroup per CU walking the tiles, next tile's DMA in flight under the epilogue) forced
+    on shapes that stress the tile roll-over, against fp32 from the bf16-rounded inputs"""
+    rt = rts["bf16"]
+    monkeypatch.setenv("MSC_GEMM_TILE", tile)
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
+    r = rnd(M, N, seed=4) if res else None
+    pre = q(x, "bf16") @ q(w, "bf16").t() + b
+    ref = [pre, torch.relu(pre), TF.gelu(pre), torch.tanh(pre), torch.sigmoid(pre)][act]
+    if res:
+        ref = ref + q(r, "bf16")
+    y = torch.full((M, N), float("nan"), device=rt.device, dtype=rt.tdtype)
+    p2 = torch.full((M, N), float("nan"), device=rt.device, dtype=rt.tdtype)
+    rt.call("msc_linear_fwd", dev(x, rt), dev(w, rt), b.to(rt.device), dev(r, rt) if res else None, y, p2, M, N, K, act, rt.dt)
+    check("y", y, ref, tol("bf16"))
+    check("pre", p2, pre, tol("bf16"))
+    # the same launch twice is bit-identical (fixed tile -> workgroup assignment, no atomics)
+    y2 = torch.empty_like(y)
+    rt.call("msc_linear_fwd", dev(x, rt), dev(w, rt), b.to(rt.device), dev(r, rt) if res else None, y2, None, M, N, K, act, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("tile", PERSIST_TILES)
+def test_persistent_linear_dgrad_fused(rts, monkeypatch, tile):
+    """extended epilogue in the persistent kernels: act' of the saved pre-activation.  (Launches that also emit per-row-block
+    column sums or BatchNorm partials never take the persistent kernels — their side buffers are sized by queries that know
+    only (rows, cols) — so the same call WITH the column sums must fall back to the 128-row tiles and still be right.)"""
+    from multimodal_sc_amd import lib as L
+    rt = rts["bf16"]
+    monkeypatch.setenv("MSC_GEMM_TILE", tile)
+    M, N, K = 40000, 192, 512
+    dy, w, pre = rnd(M, N, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(N)), rnd(M, K, seed=3)
+    pq = q(pre, "bf16").requires_grad_()
+    (TF.gelu(pq) @ q(w, "bf16").t()).backward(q(dy, "bf16"))
+    Wp = FakeParam(rt, w, "linear")
+    dx = torch.full((M, K), float("nan"), device=rt.device, dtype=rt.tdtype)
+    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, dev(pre, rt), 2, None, dx, M, N, K, rt.dt)
+    check("dx", dx, pq.grad, tol("bf16") * 2)
+    nblk = L.query("msc_linear_dgrad_colsum_rows", M, K, rt.dt)
+    assert nblk == (M + 127) // 128
+    part = torch.full((nblk, K), float("nan"), device=rt.device)
+    dx2 = torch.empty_like(dx)
+    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, dev(pre, rt), 2, part, dx2, M, N, K, rt.dt)
+    check("dx2", dx2, pq.grad, tol("bf16") * 2)
+    db = torch.empty(K, device=rt.device)
+    rt.call("msc_colsum_finalize", part, nblk, K, db, 0)
+    check("db", db, pq.grad.sum(0), tol("bf16", True) * 16)
+
+
+@pytest.mark.parametrize("tile", PERSIST_TILES)
+@pytest.mark.parametrize("case", [(6, 48, 48, 64, 128, 3, 1, 1), (5, 40, 40, 64, 256, 3, 2, 1), (3, 64, 64, 128, 256, 1, 2, 0)])
+def test_persistent_conv_fwd_dgrad(rts, monkeypatch, tile, case):
+    """implicit-GEMM convolution through the persistent kernels: forward with the fused BatchNorm partial sums, data
+    gradient with the residual add — stride 1, stride 2 (parity-class-major rows, per-tile tap schedules) and 1x1/2."""
+    from multimodal_sc_amd import lib as L
+    rt = rts["bf16"]
+    monkeypatch.setenv("MSC_GEMM_TILE", tile)
+    B, H, W, Cin, Cout, K, s, p = case
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, K, K, Cin, seed=2, scale=1 / math.sqrt(K * K * Cin))
+    xq, wq = q(x, "bf16").requires_grad_(), q(w, "bf16")
+    ref = TF.conv2d(xq.permute(0, 3, 1, 2), wq.permute(0, 3, 1, 2), None, s, p)
+    M = B * Ho * Wo
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device=rt.device, dtype=rt.tdtype)
+    Wp = FakeParam(rt, w, "conv")
+    rt.call("msc_conv2d_fwd", dev(x, rt), Wp.c, y, None, B, H, W, Cin, Cout, K, K, s, p, None, 0, rt.dt)     # persistent (no BN partials)
+    check("y", y, ref.permute(0, 2, 3, 1), tol("bf16"))
+    nrows = L.query("msc_conv2d_fwd_stat_rows", M, Cout, rt.dt)
+    part = torch.full((nrows, 2, Cout), float("nan"), device=rt.device)
+    y.fill_(float("nan"))
+    rt.call("msc_conv2d_fwd", dev(x, rt), Wp.c, y, part, B, H, W, Cin, Cout, K, K, s, p, None, 0, rt.dt)      # with partials: 128-row tiles
+    check("y2", y, ref.permute(0, 2, 3, 1), tol("bf16"))
+    check("sum", part[:, 0].sum(0), ref.sum((0, 2, 3)), 2e-3 * math.sqrt(M))
+    check("sumsq", part[:, 1].sum(0), ref.pow(2).sum((0, 2, 3)), 2e-3 * math.sqrt(M))
+    dy, rs = rnd(B, Ho, Wo, Cout, seed=5), rnd(B, H, W, Cin, seed=6)
+    ref.backward(q(dy, "bf16").permute(0, 3, 1, 2))
+    dx = torch.full((B, H, W, Cin), float("nan"), device=rt.device, dtype=rt.tdtype)
+    # dgrad output has Cin columns: the 256-column tile needs Cin >= 256, else the knob falls back inside choose_tile's rules
+    rt.call("msc_conv2d_dgrad", dev(dy, rt), Wp.t, dev(rs, rt), dx, B, H, W, Cin, Cout, K, K, s, p, None, 0, rt.dt)
+    check("dx", dx, xq.grad + q(rs, "bf16"), tol("bf16") * 2)
 
 
 # ------------------------------------------------------------------------------------------------ conv + BN
@@ -767,7 +860,7 @@ def test_full_size_invariants_c3_batch64(rts):
     wd = torch.zeros(C, 3, 3, C)
     wd[torch.arange(C), 1, 1, torch.arange(C)] = 1.0
     yo = rt.empty(Bc, H, H, C)
-    nrows = L.query("msc_conv2d_fwd_stat_rows", Bc * H * H, C)
+    nrows = L.query("msc_conv2d_fwd_stat_rows", Bc * H * H, C, rt.dt)
     part = torch.empty(nrows * 2 * C, device=dev_)
     rt.call("msc_conv2d_fwd", xi, wd.to(torch.bfloat16).to(dev_), yo, part, Bc, H, H, C, C, 3, 3, 1, 1, None, 0, rt.dt)
     torch.cuda.synchronize()

@@ -12,6 +12,7 @@ Tolerances:
              never further from it than from pure fp32 (test_bf16_end_to_end_parity_c3 explains the chaos floor).
 """
 import copy
+import os
 
 import pytest
 import torch
@@ -46,13 +47,27 @@ def _run_pair(name, B, dtype, ppo=True, with_f64=False, snr_db=10.0, taps=False)
     from oracle import model as O
     ocfg, cfg = O.named_config(name), named_config(name)
     om = O.build_oracle(ocfg, seed=1)
-    batch = O.synthetic_batch(ocfg, B, seed=2, snr_db=snr_db)
-    otaps = {} if taps else None
-    O.RELU_TAPS = otaps
-    try:
-        oout, oterms = _oracle_run(om, batch, ocfg, ppo)
-    finally:
-        O.RELU_TAPS = None
+    # The PPO surrogate min(r A, clip(r) A) is discontinuous in its gradient where the probability ratio r crosses 1 +- clip_eps:
+    # a sample sitting ON the boundary (seed 2 at 15 dB has r = 1.2003) is clipped in one implementation and not in the
+    # other for any rounding difference, which moves the whole gradient (norm ratio 1.9), not an implementation error.
+    # The batch seed is therefore the first of 2, 3, .. whose oracle ratios all keep `clip_margin` from both boundaries.
+    clip_margin = 0.03 if ocfg.codec_fp8 else 2e-3      # e4m3 rounding flips move C4's logits by up to ~1e-2
+    for seed in range(2, 8):
+        batch = O.synthetic_batch(ocfg, B, seed=seed, snr_db=snr_db)
+        otaps = {} if taps else None
+        O.RELU_TAPS = otaps
+        try:
+            oout, oterms = _oracle_run(om, batch, ocfg, ppo)
+        finally:
+            O.RELU_TAPS = None
+        if not ppo:
+            break
+        lp = torch.log_softmax(oout["logits"].detach(), -1).gather(1, batch["ppo"]["actions"].view(-1, 1)).squeeze(1)
+        ratio = torch.exp(lp - batch["ppo"]["old_logp"])
+        if min((ratio - (1 - ocfg.clip_eps)).abs().min(), (ratio - (1 + ocfg.clip_eps)).abs().min()) >= clip_margin:
+            break
+    else:
+        raise AssertionError("no batch seed keeps the PPO ratios off the clip boundaries")
     g64 = None
     if with_f64:
         om64 = copy.deepcopy(om).double()
@@ -151,8 +166,9 @@ def test_f32_end_to_end_parity(cuda, monkeypatch, name, B, snr_db, splitk):
     opsnr = O.psnr(oout["recon"], batch["image"]).mean().item()
     assert abs(met["psnr"] - opsnr) < 1e-3, (met["psnr"], opsnr)                      # decoder-PSNR parity
     assert torch.equal(m.select_action(out).cpu(), O.select_action(oout["logits"]))   # actions bit-exact
+    lt = 5e-3 if name == "C4" else 1e-4        # C4: one e4m3 grid step on a codec activation moves a value-loss term by ~3e-3
     for k in ("mse", "policy", "value", "entropy", "loss"):
-        assert abs(met[k] - oterms[k]) < (t / 10) * max(1.0, abs(oterms[k])), (k, met[k], oterms[k])
+        assert abs(met[k] - oterms[k]) < lt * max(1.0, abs(oterms[k])), (k, met[k], oterms[k])
     # ---- ReLU-mask flips: located, counted, and shown to be zero-to-rounding pre-activations
     assert set(otaps) == set(m.rt.taps), (sorted(otaps), sorted(m.rt.taps))
     flips = _relu_flips(m, otaps)
@@ -195,7 +211,12 @@ def test_f32_end_to_end_parity(cuda, monkeypatch, name, B, snr_db, splitk):
                 loosened.append(k)
             else:
                 bad.append((k, e_gpu / max(den, 1e-30), e_f32 / max(den, 1e-30), relf, "flip proven" if flip_downstream_of(k) else "NO flip"))
-    print(f"[{name} snr={snr_db} splitk={splitk}] relu flips: {flips}; tensors on the loose bound: {len(loosened)}")
+    line = f"[{name} B={B} snr={snr_db} splitk={splitk}] relu flips (tag: count, |pre|/max): {flips}; tensors on the loose bound: {len(loosened)}"
+    print(line)
+    rec = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(rec):                       # kept as evidence next to the test log (profiles/r2_relu_flips.txt)
+        with open(os.path.join(rec, "relu_flips.txt"), "a") as fh:
+            fh.write(line + "\n")
     assert not bad, (bad[:8], flips)
     if loosened:
         a = torch.cat([gg[k].double().flatten() for k in g64])

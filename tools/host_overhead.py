@@ -5,11 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodal_sc_amd.model import MultimodalSC, named_config
 from multimodal_sc_amd.trainer import Trainer
-from oracle import model as O
+from multimodal_sc_amd.synthetic import synthetic_batch
 cfg = named_config("C3")
 m = MultimodalSC(cfg, "bf16", "cuda:0")
 tr = Trainer(m)
-cb = O.synthetic_batch(O.named_config("C3"), 64, seed=1)
+cb = synthetic_batch(cfg, 64, seed=1)
 b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cb.items() if k != "ppo"}
 b["ppo"] = {k: v.cuda() for k, v in cb["ppo"].items()}
 b["noise"] = b["fading"] = None

@@ -10,7 +10,7 @@ for dt in ("f32", "bf16"):
         w = (torch.randn(Cout, 3, 3, Cin, generator=g) / 50).to(rt.tdtype).cuda()
         Ho = H
         M = B * Ho * Ho
-        nrows = L.query("msc_conv2d_fwd_stat_rows", M, Cout)
+        nrows = L.query("msc_conv2d_fwd_stat_rows", M, Cout, rt.dt)
         outs = []
         for use in (0, 1):
             y = torch.zeros(B, Ho, Ho, Cout, dtype=rt.tdtype, device="cuda")
