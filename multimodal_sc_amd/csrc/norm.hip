@@ -20,24 +20,29 @@ struct FinArgs {
   float* out0; float* out1; float* acc0; float* acc1; int accumulate;
 };
 
-template <int MODE>
+// CPB channels per block x RL = 256/CPB row lanes.  These kernels sit on the critical chain between every convolution and
+// its BatchNorm apply (and between the two BatchNorm-backward passes): a few-microsecond, latency-bound reduction, so
+// the host picks CPB = 2 (128 row lanes, 4x more blocks) when there are many partial rows — the per-thread chain of
+// dependent load rounds is what the kernel's time consists of.
+template <int MODE, int CPB>
 __global__ __launch_bounds__(256) void finalize2_kernel(const FinArgs a) {
-  __shared__ double red[2][32][8];
-  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
+  constexpr int RL = 256 / CPB;
+  __shared__ double red[2][RL][CPB];
+  const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB;
+  const int c = blockIdx.x * CPB + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < a.C) {
     // 4 independent load pairs per trip: the serial part is the fp64 add chain, not a chain of memory round trips
     int b = rl;
-    for (; b + 96 < a.nblk; b += 128) {
+    for (; b + 3 * RL < a.nblk; b += 4 * RL) {
       const float x0 = a.partial[(long)b * 2 * a.C + c], y0 = a.partial[(long)b * 2 * a.C + a.C + c];
-      const float x1 = a.partial[(long)(b + 32) * 2 * a.C + c], y1 = a.partial[(long)(b + 32) * 2 * a.C + a.C + c];
-      const float x2 = a.partial[(long)(b + 64) * 2 * a.C + c], y2 = a.partial[(long)(b + 64) * 2 * a.C + a.C + c];
-      const float x3 = a.partial[(long)(b + 96) * 2 * a.C + c], y3 = a.partial[(long)(b + 96) * 2 * a.C + a.C + c];
+      const float x1 = a.partial[(long)(b + RL) * 2 * a.C + c], y1 = a.partial[(long)(b + RL) * 2 * a.C + a.C + c];
+      const float x2 = a.partial[(long)(b + 2 * RL) * 2 * a.C + c], y2 = a.partial[(long)(b + 2 * RL) * 2 * a.C + a.C + c];
+      const float x3 = a.partial[(long)(b + 3 * RL) * 2 * a.C + c], y3 = a.partial[(long)(b + 3 * RL) * 2 * a.C + a.C + c];
       s1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
       s2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
     }
-    for (; b < a.nblk; b += 32) {
+    for (; b < a.nblk; b += RL) {
       s1 += (double)a.partial[(long)b * 2 * a.C + c];
       s2 += (double)a.partial[(long)b * 2 * a.C + a.C + c];
     }
@@ -45,9 +50,13 @@ __global__ __launch_bounds__(256) void finalize2_kernel(const FinArgs a) {
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
   __syncthreads();
+  // fixed-order tree over the row lanes (bitwise reproducible), then lane 0 of each channel finishes
+  for (int h = RL / 2; h >= 1; h >>= 1) {
+    if (rl < h) { red[0][rl][cl] += red[0][rl + h][cl]; red[1][rl][cl] += red[1][rl + h][cl]; }
+    __syncthreads();
+  }
   if (rl != 0 || c >= a.C) return;
-  s1 = 0.0; s2 = 0.0;
-  for (int r = 0; r < 32; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
+  s1 = red[0][0][cl]; s2 = red[1][0][cl];
   if constexpr (MODE == FIN_BN_FWD) {
     // E[x^2]-E[x]^2 formed in double so the cancellation does not cost fp32 digits
     const double m = s1 * a.inv_count;
@@ -405,7 +414,8 @@ extern "C" int msc_bn_finalize(const float* partial, int nblk, int C, int64_t co
   memset(&a, 0, sizeof(a));
   a.partial = partial; a.nblk = nblk; a.C = C; a.inv_count = 1.0 / (double)count; a.eps = eps;
   a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd; a.scale = scale; a.shift = shift;
-  hipLaunchKernelGGL(finalize2_kernel<FIN_BN_FWD>, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, a);
+  if (nblk > 128) hipLaunchKernelGGL((finalize2_kernel<FIN_BN_FWD, 2>), dim3(cdiv(C, 2)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((finalize2_kernel<FIN_BN_FWD, 8>), dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, a);
   return msc_launch_status();
 }
 
@@ -414,7 +424,8 @@ static void launch_fin_sums(const float* partial, int nblk, int C, float* out0, 
   FinArgs a;
   memset(&a, 0, sizeof(a));
   a.partial = partial; a.nblk = nblk; a.C = C; a.out0 = out0; a.out1 = out1; a.acc0 = acc0; a.acc1 = acc1; a.accumulate = accumulate;
-  hipLaunchKernelGGL(finalize2_kernel<FIN_SUMS>, dim3(cdiv(C, 8)), dim3(256), 0, st, a);
+  if (nblk > 128) hipLaunchKernelGGL((finalize2_kernel<FIN_SUMS, 2>), dim3(cdiv(C, 2)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((finalize2_kernel<FIN_SUMS, 8>), dim3(cdiv(C, 8)), dim3(256), 0, st, a);
 }
 
 extern "C" int msc_bn_apply(const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t rows,

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""GPU time of the phases of one training step in the NORMAL multi-stream mode (no profiler): HIP events recorded on the
+main stream when landmark kernels are enqueued (encoders fwd | fusion fwd | codec+heads fwd+loss | codec+heads bwd |
+fusion bwd | encoder bwd + optimizer), median over steps."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_sc_amd.model import MultimodalSC, named_config
+from multimodal_sc_amd.synthetic import synthetic_batch
+from multimodal_sc_amd.trainer import Trainer
+cfg = named_config(os.environ.get("CFG", "C3"))
+B = int(os.environ.get("B", "64"))
+m = MultimodalSC(cfg, "bf16", "cuda:0")
+tr = Trainer(m)
+cb = synthetic_batch(cfg, B, seed=1)
+b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cb.items() if k != "ppo"}
+b["ppo"] = {k: v.cuda() for k, v in cb["ppo"].items()}
+b["noise"] = b["fading"] = None
+marks = ["msc_image_to_nhwc", "msc_tokens_assemble", "msc_meanpool_fwd", "msc_recon_loss", "msc_meanpool_bwd", "msc_tokens_split", "msc_adam_step"]
+names = ["encoders fwd", "fusion fwd", "codec+heads fwd", "loss + codec/heads bwd", "fusion bwd", "encoder bwd"]
+rt = m.rt
+orig = rt.call
+rec = []
+def call(name, *a):
+    if name in marks and (name != "msc_adam_step" or not rec or rec[-1][0] != "msc_adam_step"):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        rec.append((name, e))
+    return orig(name, *a)
+rt.call = call
+for _ in range(4):
+    tr.step(b)
+torch.cuda.synchronize()
+rec.clear()
+steps = 12
+for _ in range(steps):
+    tr.step(b)
+torch.cuda.synchronize()
+per = {n: [] for n in names}
+tot = []
+i = 0
+while i + len(marks) <= len(rec):
+    chunk = rec[i:i + len(marks)]
+    if [c[0] for c in chunk] != marks:
+        i += 1
+        continue
+    for k, n in enumerate(names):
+        per[n].append(chunk[k][1].elapsed_time(chunk[k + 1][1]))
+    tot.append(chunk[0][1].elapsed_time(chunk[-1][1]))
+    i += len(marks)
+print(f"{cfg.n_tokens} tokens, {B} frames: step (first landmark -> optimizer) median {statistics.median(tot):.3f} ms over {len(tot)} steps")
+for n in names:
+    print(f"  {n:26s} {statistics.median(per[n]):7.3f} ms")
