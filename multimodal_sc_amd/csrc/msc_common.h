@@ -46,6 +46,11 @@ template <> struct vecf<float> {
   __device__ __forceinline__ void store(float* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  __device__ __forceinline__ void store_nt(float* p) const {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 w = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
+  }
 };
 template <> struct vecf<bf16_t> {
   float v[8];
@@ -64,6 +69,15 @@ template <> struct vecf<bf16_t> {
     for (int i = 0; i < 4; ++i)
       w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // streaming (non-temporal) form: the line is not kept in the L2 on its way out
+  __device__ __forceinline__ void store_nt(bf16_t* p) const {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
   }
 };
 

@@ -16,14 +16,15 @@ dev = rt.device
 rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 B = 64
 M = B * 306
-shapes = {"qkv": (M, 1536, 512), "fc2": (M, 512, 2048), "big": (8192, 8192, 4096)}
+shapes = {"qkv": (M, 1536, 512), "fc2": (M, 512, 2048), "big": (8192, 8192, 4096), "fc1": (M, 2048, 512), "fc1plain": (M, 2048, 512)}
 for name in (sys.argv[1:] or ["qkv", "fc2", "big"]):
     Mm, N, K = shapes[name]
     x, w, b, y = rnd(Mm, K), rnd(N, K), torch.randn(N, device=dev), rnd(Mm, N)
-    for tile in ("128x128", "256x128", "256x256"):
+    pre = rnd(Mm, N) if name == "fc1" else None          # fc1: GELU epilogue + second (pre-activation) output
+    for tile in ("128x128", "128x64", "256x256"):
         os.environ["MSC_GEMM_TILE"] = tile
         for _ in range(3):
-            rt.call("msc_linear_fwd", x, w, b, None, y, None, Mm, N, K, 0, rt.dt)
+            rt.call("msc_linear_fwd", x, w, b, None, y, pre, Mm, N, K, 2 if name == "fc1" else 0, rt.dt)
         torch.cuda.synchronize()
         bm, bn = (int(v) for v in tile.split("x"))
         ntiles = -(-Mm // bm) * -(-N // bn)
