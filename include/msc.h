@@ -88,8 +88,9 @@ int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K, int dtype);
 int msc_linear_dgrad(const void* dy, const void* wt, const void* dact_ref, int dact, float* colsum_partial, void* dx,
                      int M, int N, int K, int dtype, void* stream);
 int msc_colsum_finalize(const float* partial, int nblk, int64_t cols, float* out, int accumulate, void* stream);
-/* dw[N,K] (fp32) = dy[M,N]^T x[M,K] */
-int msc_linear_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int M, int N,
+/* dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db (optional, fp32 [N], N % 4 == 0) = column sums of dy = the bias gradient, produced by
+ * the same launch (one extra MFMA per dy fragment against a ones fragment in the first column tile) — no separate pass over dy */
+int msc_linear_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int64_t ws_bytes, int M, int N,
                      int K, int accumulate, int dtype, void* stream);
 
 /* General strided-batched GEMM used by the unfused attention path:

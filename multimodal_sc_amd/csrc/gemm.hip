@@ -46,6 +46,8 @@ struct GemmParams {
   int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
   unsigned long long* stamps;   // GEMM_STAMP diagnostic build only (else null and unused)
   int bm_cap;                   // host only: largest tile height the launch may use (0 = no cap)
+  float* rowsum;                // weight-gradient launches (both operands mn-major): fp32 [nsplit][M] sums over the reduction of the
+                                // A operand's rows = the bias gradient (dy^T 1), produced by one extra MFMA against a ones fragment
   int xcd_split;                // split-K launches: all tiles of one K slice on one XCD (see the kernel's index mapping)
   const void* dref; int dact;   // epilogue: multiply by act'(dref[m][n]) (fused activation backward)
   float* colsum;                // epilogue: per-row-block column sums of the stored output, [tile_m][N]
@@ -576,6 +578,18 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // Bias gradient inside the weight-gradient GEMM: db[n] = sum_m dy[m][n] is the row sum of the A operand over the
+    // reduction.  The A fragments are in registers anyway, so the workgroups of the FIRST column tile (wave column 0) run
+    // one extra MFMA per fragment against an all-ones B fragment: every column of that product is the row sum.
+    constexpr bool ROWSUM = (AMODE == OPM_DENSE_MN && BMODE == OPM_DENSE_MN);
+    const bool do_rowsum = ROWSUM && p.rowsum != nullptr && cg.tile_n == 0 && wn == 0;      // wave-uniform
+    f32x16_t racc[ROWSUM ? MI : 1];
+    if constexpr (ROWSUM) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) racc[i][r] = 0.f;
+    }
 
 #ifdef GEMM_STAMP
     const unsigned long long st_k0 = STAMP_NOW();
@@ -636,6 +650,15 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          if constexpr (ROWSUM) {
+            if (do_rowsum) {
+              mfma_bf16x8_t ones;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+              for (int i = 0; i < MI; ++i) racc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, racc[i], 0, 0, 0);
+            }
+          }
           if constexpr (SPREAD) {      // this sub-step's share of the next step's DMA pieces, behind its MFMAs
             if (more) {
               if (ks == 0) issue_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, NPS * 1 / NKS>{});
@@ -661,6 +684,12 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm
 #pragma unroll
             for (int j = 0; j < NI; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          if constexpr (ROWSUM) {
+            if (do_rowsum) {
+#pragma unroll
+              for (int i = 0; i < MI; ++i) racc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], 1.0f, racc[i], 0, 0, 0);
+            }
+          }
         }
       }
       if (more) issue_close();
@@ -692,6 +721,19 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm
   } while (0)
 
   // ---------------------------------------------------------------- epilogue
+  // (0) bias-gradient partials of this K slice (weight-gradient launches): lanes 0 and 32 hold the 32 row sums of a tile
+  if constexpr (ROWSUM) {
+    if (do_rowsum && lr == 0) {
+      float* rs = p.rowsum + (long)split * p.M;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < p.M) rs[row] = racc[i][r];
+        }
+    }
+  }
   // (1) BatchNorm partial statistics straight from the fp32 accumulators (conv forward only)
   if (p.stats) {
     float* red = reinterpret_cast<float*>(ep_mem);  // [NWM][2 stat][BN]
@@ -884,9 +926,15 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm
 // slabs) would otherwise walk the slabs serially from a handful of threads.  Group y sums slabs y, y+RY, ...; the groups
 // are combined through LDS in the order 0..RY-1.
 template <int RY>
-__global__ __launch_bounds__(64 * RY) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n4, int nsplit, int accumulate) {
+__global__ __launch_bounds__(64 * RY) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n4, int nsplit, int accumulate,
+                                                                const float* __restrict__ slab2, float* __restrict__ out2, long n4b, unsigned blocks1) {
   __shared__ float4 part[RY][64];
-  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  // blocks past blocks1 reduce the second (small) job of the launch: the bias-gradient row sums [nsplit][4*n4b] -> out2
+  long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (blockIdx.x >= blocks1) {
+    slab = slab2; out = out2; n4 = n4b;
+    i = (long)(blockIdx.x - blocks1) * 64 + threadIdx.x;
+  }
   const int y = threadIdx.y;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
@@ -1050,37 +1098,44 @@ static inline int esize(int dtype) { return dtype == MSC_F32 ? 4 : 2; }
 static inline bool fits32(long elems, int dtype) { return elems * esize(dtype) < 0x7ffffff0L; }
 
 extern "C" int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len) {
-  return (int64_t)mscplan::plan_split(rows_out, cols_out, reduce_len) * rows_out * cols_out * 4;
+  return mscplan::wgrad_workspace_bytes(rows_out, cols_out, reduce_len);
 }
 
-static int finish_wgrad(GemmParams& p, float* dw, float* ws, int64_t ws_bytes, long reduce_len, int accumulate,
+// db (optional, linear layers): bias gradient [M] = row sums of the A operand, produced by the same launch (p.rowsum) and
+// reduced over the K slices by extra blocks of the reduce launch
+static int finish_wgrad(GemmParams& p, float* dw, float* db, float* ws, int64_t ws_bytes, long reduce_len, int accumulate,
                         int dtype, hipStream_t st, int (*launch)(const GemmParams&, int, int, hipStream_t), int kstep_bytes) {
   const mscplan::WgradSplit w = mscplan::wgrad_split(p.M, p.N, reduce_len, kstep_bytes / esize(dtype));
   const int ns = w.ns;
-  if ((int64_t)ns * p.M * p.N * 4 > ws_bytes || !ws) return MSC_ERR_BAD_ARG;
-  if (((long)p.M * p.N) % 4) return MSC_ERR_BAD_ARG;
+  if ((int64_t)ns * p.M * (p.N + 1) * 4 > ws_bytes || !ws) return MSC_ERR_BAD_ARG;
+  if (((long)p.M * p.N) % 4 || (db && p.M % 4)) return MSC_ERR_BAD_ARG;
+  float* ws_rows = ws + (long)ns * p.M * p.N;        // [ns][M] behind the weight slabs
+  p.rowsum = db ? ws_rows : nullptr;
   p.nsplit = ns;
   p.tiles_per_split = w.tps;
   p.xcd_split = w.xcd_split;
   p.C = ws;
   p.ldc = p.N;
   p.out_f32 = 1;
-  if (ns == 1 && !accumulate) {   // no slab, no reduce pass: the GEMM epilogue writes dw itself
+  if (ns == 1 && !accumulate) {   // no slab, no reduce pass: the GEMM epilogue writes dw (and db) itself
     p.C = dw;
+    p.rowsum = db;
     return launch(p, 1, dtype, st);
   }
   int rc = launch(p, 1, dtype, st);
   if (rc != MSC_OK) return rc;
   const long n4 = (long)p.M * p.N / 4;
   const unsigned blocks = (unsigned)cdiv(n4, 64);
+  const long n4b = db ? p.M / 4 : 0;
+  const unsigned grid = blocks + (unsigned)cdiv(n4b, 64);
   // slab groups per block: as many as keep >= ~4 waves per CU busy, at most the slab count
   int ry = 1;
   while (ry < 16 && ry * 2 <= ns && (long)blocks * ry < 4096) ry *= 2;
-  if (ry == 1) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(64, 1), 0, st, ws, dw, n4, ns, accumulate);
-  else if (ry == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(blocks), dim3(64, 2), 0, st, ws, dw, n4, ns, accumulate);
-  else if (ry == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(64, 4), 0, st, ws, dw, n4, ns, accumulate);
-  else if (ry == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(blocks), dim3(64, 8), 0, st, ws, dw, n4, ns, accumulate);
-  else hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(blocks), dim3(64, 16), 0, st, ws, dw, n4, ns, accumulate);
+  if (ry == 1) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(grid), dim3(64, 1), 0, st, ws, dw, n4, ns, accumulate, ws_rows, db, n4b, blocks);
+  else if (ry == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(grid), dim3(64, 2), 0, st, ws, dw, n4, ns, accumulate, ws_rows, db, n4b, blocks);
+  else if (ry == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(grid), dim3(64, 4), 0, st, ws, dw, n4, ns, accumulate, ws_rows, db, n4b, blocks);
+  else if (ry == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(grid), dim3(64, 8), 0, st, ws, dw, n4, ns, accumulate, ws_rows, db, n4b, blocks);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(grid), dim3(64, 16), 0, st, ws, dw, n4, ns, accumulate, ws_rows, db, n4b, blocks);
   return msc_launch_status();
 }
 
@@ -1171,7 +1226,7 @@ extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.M = Cout; p.N = KH * KW * Cin; p.K = B * Ho * Wo;
   p.lda = Cout;
   if (set_conv_geom(p, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad) != MSC_OK) return MSC_ERR_BAD_ARG;
-  return finish_wgrad(p, dw, ws, ws_bytes, p.K, accumulate, dtype, (hipStream_t)stream,
+  return finish_wgrad(p, dw, nullptr, ws, ws_bytes, p.K, accumulate, dtype, (hipStream_t)stream,
                       launch_gemm_dt<OPM_DENSE_MN, OPM_CONV_WGRAD>, 64);
 }
 
@@ -1205,7 +1260,7 @@ extern "C" int msc_linear_dgrad(const void* dy, const void* wt, const void* dact
   return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
 }
 
-extern "C" int msc_linear_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int M, int N,
+extern "C" int msc_linear_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int64_t ws_bytes, int M, int N,
                                 int K, int accumulate, int dtype, void* stream) {
   MSC_CHECK_ARG(x && dy && dw && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
@@ -1214,7 +1269,7 @@ extern "C" int msc_linear_wgrad(const void* x, const void* dy, float* dw, float*
   GemmParams p = base_params();
   p.A = dy; p.B = x;
   p.M = N; p.N = K; p.K = M; p.lda = N; p.ldb = K;
-  return finish_wgrad(p, dw, ws, ws_bytes, M, accumulate, dtype, (hipStream_t)stream,
+  return finish_wgrad(p, dw, db, ws, ws_bytes, M, accumulate, dtype, (hipStream_t)stream,
                       launch_gemm_dt<OPM_DENSE_MN, OPM_DENSE_MN>, GEMM_NP_KB);
 }
 

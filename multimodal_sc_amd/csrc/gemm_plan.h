@@ -133,6 +133,11 @@ static inline int plan_split(long rows_out, long cols_out, long reduce_len) {
   return (int)want;
 }
 
+// fp32 workspace of a weight-gradient launch: `planned` slabs of rows_out x cols_out + `planned` rows of bias-gradient partials
+static inline int64_t wgrad_workspace_bytes(long rows_out, long cols_out, long reduce_len) {
+  return (int64_t)plan_split(rows_out, cols_out, reduce_len) * rows_out * (cols_out + 1) * 4;
+}
+
 struct WgradSplit { int ns, tps, xcd_split; int64_t ws_bytes; };
 // kt = reduction elements per K step of the kernel variant that runs the launch
 static inline WgradSplit wgrad_split(long rows_out, long cols_out, long reduce_len, int kt) {
@@ -143,7 +148,7 @@ static inline WgradSplit wgrad_split(long rows_out, long cols_out, long reduce_l
   w.ns = (int)cdivl(nk, w.tps);
   static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;
   w.xcd_split = (xs && w.ns >= 8 && w.ns % 8 == 0) ? 1 : 0;
-  w.ws_bytes = (int64_t)planned * rows_out * cols_out * 4;
+  w.ws_bytes = (int64_t)planned * rows_out * (cols_out + 1) * 4;
   return w;
 }
 

@@ -47,6 +47,7 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
 
 
 _STEM_WGRAD_MAIN = os.environ.get("MSC_STEM_WGRAD_MAIN", "1") != "0"
+_FUSED_BIAS = os.environ.get("MSC_FUSED_BIAS", "1") != "0"    # A/B knob: 0 = bias gradients by separate column-sum launches
 
 
 def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, mean, rstd, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad,
@@ -181,12 +182,15 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
     else:
         d = dy2d
     def side_work():
-        if b is not None and not bias_done:
-            ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N), per_stream=False)
-            rt.call_side("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)      # bias gradient: off the critical path
+        # weight gradient and (same launch: the row sums of dy ride on one extra MFMA per fragment) bias gradient
         wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
         wsw = rt.workspace("wgrad", wsb, per_stream=False)     # only the side stream touches it
-        rt.call_side("msc_linear_wgrad", x2d, d, w.g, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
+        db = b.g if (b is not None and not bias_done) else None
+        if db is not None and not _FUSED_BIAS:
+            ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N), per_stream=False)
+            rt.call_side("msc_colsum", d, db, ws, M, N, rt.accumulate, rt.dt)
+            db = None
+        rt.call_side("msc_linear_wgrad", x2d, d, w.g, db, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
 
     # (enqueueing the dgrad BEFORE the side-stream launches was measured: 0.5 % slower — the side stream then also
     # waits for the dgrad)
@@ -257,12 +261,9 @@ class LinearFP8(torch.autograd.Function):
             rt.call("msc_act_bwd", dy2d, ref, d, M * N, act, rt.dt)
         else:
             d = dy2d
-        if b is not None:
-            ws = rt.workspace("colsum", L.query("msc_colsum_workspace_bytes", M, N), per_stream=False)
-            rt.call_side("msc_colsum", d, b.g, ws, M, N, rt.accumulate, rt.dt)
         wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
         wsw = rt.workspace("wgrad", wsb, per_stream=False)
-        rt.call_side("msc_linear_wgrad", xh, d, w.g, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
+        rt.call_side("msc_linear_wgrad", xh, d, w.g, b.g if b is not None else None, wsw, wsb, M, N, K, rt.accumulate, rt.dt)
         dx = None
         if need_dx:
             dx = rt.empty(M, K)
@@ -387,10 +388,10 @@ class FusionLayerFn(torch.autograd.Function):
         hd = D // h
         x2d, mu1, rs1, h1, qkv, P, o, x1, mu2, rs2, h2, upre, u = ctx.saved_tensors
         dx2 = dy.reshape(B * T, D).contiguous()
-        # fc2's dgrad epilogue applies GELU' (from the saved pre-activation) and emits fc1's bias gradient
-        dpre = linear_bwd(rt, dx2, u, None, p["fc2w"], p["fc2b"], L.ACT_NONE, prev_act=L.ACT_GELU, prev_ref=upre,
-                          prev_bias=p["fc1b"])
-        dh2 = linear_bwd(rt, dpre, h2, None, p["fc1w"], p["fc1b"], L.ACT_NONE, bias_done=True)
+        # fc2's dgrad epilogue applies GELU' (from the saved pre-activation); fc1's bias gradient = row sums of dpre, which
+        # fc1's weight-gradient GEMM produces on the side (no column-sum epilogue + finalize launch on the main chain)
+        dpre = linear_bwd(rt, dx2, u, None, p["fc2w"], p["fc2b"], L.ACT_NONE, prev_act=L.ACT_GELU, prev_ref=upre)
+        dh2 = linear_bwd(rt, dpre, h2, None, p["fc1w"], p["fc1b"], L.ACT_NONE)
         dx1 = layernorm_bwd(rt, dh2, x1, mu2, rs2, p["ln2g"], p["ln2b"], dadd=dx2)       # + residual branch
         do = linear_bwd(rt, dx1, o, None, p["projw"], p["projb"], L.ACT_NONE)
         dqkv = attention_bwd(rt, do, qkv, o, P, B, T, h, hd)

@@ -78,8 +78,13 @@ int main(int argc, char** argv) {
       const long nk = mscplan::cdivl(R, kt2);
       CHECK(w.ns >= 1 && w.ns <= 128);
       CHECK((long)w.ns * w.tps >= nk && (long)(w.ns - 1) * w.tps < nk);
-      CHECK(w.ws_bytes >= (int64_t)w.ns * M2 * N2 * 4);
-      CHECK((int64_t)mscplan::plan_split(M2, N2, R) * M2 * N2 * 4 == w.ws_bytes);    // msc_wgrad_workspace_bytes
+      CHECK(w.ws_bytes >= (int64_t)w.ns * M2 * (N2 + 1) * 4);                         // weight slabs + bias-gradient rows
+      CHECK(mscplan::wgrad_workspace_bytes(M2, N2, R) == w.ws_bytes);                 // msc_wgrad_workspace_bytes
+      if (w.ws_bytes < (1 << 24)) {            // every slab corner and the last bias-partial row the launch writes
+        std::vector<float> ws((size_t)(w.ws_bytes / 4));
+        for (int sidx = 0; sidx < w.ns; ++sidx) ws[(size_t)((long)sidx * M2 * N2 + (M2 - 1) * N2 + (N2 - 1))] = 1.f;
+        ws[(size_t)((long)w.ns * M2 * N2 + (long)(w.ns - 1) * M2 + (M2 - 1))] = 2.f;
+      }
       if (w.xcd_split) {
         ++n_xcd;
         CHECK(w.ns % 8 == 0);

@@ -850,8 +850,8 @@ def test_full_size_invariants_c3_batch64(rts):
     dw1, dw2 = torch.empty(N, K, device=dev_), torch.empty(N, K, device=dev_)
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
     ws = torch.empty(wsb // 4, device=dev_)
-    rt.call("msc_linear_wgrad", x, y1, dw1, ws, wsb, M, N, K, 0, rt.dt)
-    rt.call("msc_linear_wgrad", x * 2, y1, dw2, ws, wsb, M, N, K, 0, rt.dt)
+    rt.call("msc_linear_wgrad", x, y1, dw1, None, ws, wsb, M, N, K, 0, rt.dt)
+    rt.call("msc_linear_wgrad", x * 2, y1, dw2, None, ws, wsb, M, N, K, 0, rt.dt)
     torch.cuda.synchronize()
     assert torch.equal(dw2, 2 * dw1)
     # delta-kernel convolution == identity (64 x 56 x 56 x 64)

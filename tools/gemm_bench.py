@@ -43,7 +43,7 @@ for name, N, K, act, res, pre in [("qkv", 1536, 512, 0, 0, 0), ("proj+res", 512,
     dw = torch.empty(N, K, device=dev)
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
     ws = torch.empty(wsb // 4, device=dev)
-    t = timeit(lambda: rt.call("msc_linear_wgrad", x, dy, dw, ws, wsb, M, N, K, 0, rt.dt))
+    t = timeit(lambda: rt.call("msc_linear_wgrad", x, dy, dw, None, ws, wsb, M, N, K, 0, rt.dt))
     rows.append((f"linear_wgrad {name}", t, fl))
 
 # ---- convolutions (ResNet-18 @224 + BEV)

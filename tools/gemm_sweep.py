@@ -45,7 +45,7 @@ for name, N, K in [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), (
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M) * 4
     ws = torch.empty(wsb // 4, device=dev)
     cases.append((f"lin_wgrad {name} {N}x{K}", fl, (lambda x=x, dy=dy, dw=dw, ws=ws, wsb=wsb, N=N, K=K:
-                  rt.call("msc_linear_wgrad", x, dy, dw, ws, wsb, M, N, K, 0, rt.dt)), MN))
+                  rt.call("msc_linear_wgrad", x, dy, dw, None, ws, wsb, M, N, K, 0, rt.dt)), MN))
 convs = [("conv1 7x7/2", 224, 8, 64, 7, 2, 3), ("l1 3x3", 56, 64, 64, 3, 1, 1), ("l2 3x3/2", 56, 64, 128, 3, 2, 1), ("l2 3x3", 28, 128, 128, 3, 1, 1),
          ("l3 3x3/2", 28, 128, 256, 3, 2, 1), ("l3 3x3", 14, 256, 256, 3, 1, 1), ("l4 3x3/2", 14, 256, 512, 3, 2, 1), ("l4 3x3", 7, 512, 512, 3, 1, 1),
          ("bev1 3x3/2", 128, 64, 128, 3, 2, 1), ("bev2 3x3/2", 64, 128, 256, 3, 2, 1), ("bev3 3x3/2", 32, 256, 512, 3, 2, 1)]
