@@ -189,12 +189,12 @@ int msc_counter_add(int64_t* ctr, int64_t inc, void* stream);
  * SemanticEncoder power normalisation + Channel (AWGN / Rayleigh).  x,y: T [B][k]; noise/fading:
  * fp32 [B][k] or NULL (then Philox4x32-10 with `seed`); snr_db: fp32 [B]; scale: fp32 [B] (saved). */
 /* In-kernel noise: Philox4x32-10 with key = seed (lo, hi words; the host side puts the DP rank in the high word) and
- * counter = (block lo, block hi, stream_id + 2*draw_hi, draw_lo).  draw_dev (optional, device int64): a draw counter the
- * caller bumps (msc_counter_add) after every forward, read by the kernel — fresh noise per forward, also under hipGraph
- * replay; seed, rank and draw never share a word, so (seed 1, draw 0) and (seed 0, draw 1) are different streams. */
+ * counter = (block lo, block hi, stream_id + 2*draw_hi, draw_lo) with draw = `draw` (host-side count of forwards, eager
+ * launches) + draw_dev[0] (optional device int64 the caller bumps with msc_counter_add after every forward — used where the
+ * launch sequence is replayed from a hipGraph and a host value would be frozen): fresh noise per forward either way; seed, rank and draw never share a word, so (seed 1, draw 0) and (seed 0, draw 1) are different streams. */
 int msc_channel_fwd(const void* x, const float* noise, const float* fading, const float* snr_db, void* y,
-                    float* scale, int B, int k, int mode, uint64_t seed, const int64_t* draw_dev, int dtype,
-                    void* stream);
+                    float* scale, int B, int k, int mode, uint64_t seed, uint64_t draw, const int64_t* draw_dev,
+                    int dtype, void* stream);
 int msc_channel_bwd(const void* dy, const void* x, const float* scale, void* dx, int B, int k, int dtype,
                     void* stream);
 int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, uint64_t draw, void* stream);

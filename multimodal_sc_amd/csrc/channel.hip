@@ -35,9 +35,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void channel_fwd_kernel(const T* __restrict__ x, const float* __restrict__ noise,
                                                           const float* __restrict__ fading, const float* __restrict__ snr_db,
                                                           T* __restrict__ y, float* __restrict__ scale, int B, int k, int mode,
-                                                          uint64_t seed, const int64_t* __restrict__ draw_dev) {
-  // device-side draw counter (bumped by the caller after every forward, also under hipGraph replay): fresh noise per draw
-  const uint64_t draw = draw_dev ? (uint64_t)*draw_dev : 0ull;
+                                                          uint64_t seed, uint64_t draw, const int64_t* __restrict__ draw_dev) {
+  // draw number = host-supplied count (eager launches) + device-side counter (bumped by the caller after every forward where
+  // the launch sequence is replayed from a hipGraph and a host value would be frozen): fresh noise per forward either way
+  if (draw_dev) draw += (uint64_t)*draw_dev;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -130,14 +131,14 @@ __global__ void philox_fill_kernel(float* __restrict__ out, long nquads, uint64_
 }
 
 extern "C" int msc_channel_fwd(const void* x, const float* noise, const float* fading, const float* snr_db, void* y, float* scale,
-                               int B, int k, int mode, uint64_t seed, const int64_t* draw_dev, int dtype, void* stream) {
+                               int B, int k, int mode, uint64_t seed, uint64_t draw, const int64_t* draw_dev, int dtype, void* stream) {
   MSC_CHECK_ARG(x && snr_db && y && scale && B > 0 && k > 0 && k % 4 == 0 && k <= 64 * 4 * CH_MAXQ);
   MSC_CHECK_ARG(mode == MSC_CH_AWGN || mode == MSC_CH_RAYLEIGH);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSC_F32)
-    hipLaunchKernelGGL(channel_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)x, noise, fading, snr_db, (float*)y, scale, B, k, mode, seed, draw_dev);
+    hipLaunchKernelGGL(channel_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)x, noise, fading, snr_db, (float*)y, scale, B, k, mode, seed, draw, draw_dev);
   else if (dtype == MSC_BF16)
-    hipLaunchKernelGGL(channel_fwd_kernel<bf16_t>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const bf16_t*)x, noise, fading, snr_db, (bf16_t*)y, scale, B, k, mode, seed, draw_dev);
+    hipLaunchKernelGGL(channel_fwd_kernel<bf16_t>, dim3(cdiv(B, 4)), dim3(256), 0, st, (const bf16_t*)x, noise, fading, snr_db, (bf16_t*)y, scale, B, k, mode, seed, draw, draw_dev);
   else
     return MSC_ERR_BAD_ARG;
   return msc_launch_status();

@@ -322,13 +322,13 @@ __global__ void permute3_cast_batched_kernel(const float* __restrict__ P, T* __r
 // ---------------------------------------------------------------- fused Adam (+ low-precision shadow copy)
 template <typename T>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            T* __restrict__ shadow, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
-                            float bc2_sqrt, float gscale, const int64_t* __restrict__ step_dev) {
-  if (step_dev) {   // step counter kept on the device (hipGraph replay): bias corrections computed here
-    const float st = (float)*step_dev;
-    bc1 = 1.f - powf(b1, st);
-    bc2_sqrt = sqrtf(1.f - powf(b2, st));
-  }
+                            T* __restrict__ shadow, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                            float gscale, const int64_t* __restrict__ step_dev) {
+  // bias corrections are computed HERE from the step number in both modes (host argument for eager launches, device counter
+  // under hipGraph replay), so the two launch paths are bit-identical
+  const float st = step_dev ? (float)*step_dev : (float)step;
+  const float bc1 = 1.f - powf(b1, st);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, st));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale;
     float pi = p[i];
@@ -437,9 +437,7 @@ extern "C" int msc_permute3_cast_batched(const float* P, void* TR, const int64_t
 extern "C" int msc_adam_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step, const int64_t* step_dev, float grad_scale, int dtype, void* stream) {
   MSC_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || step_dev));
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   DISPATCH_T(dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                                       (T*)(dtype == MSC_F32 ? nullptr : shadow), (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, step_dev));
+                                       (T*)(dtype == MSC_F32 ? nullptr : shadow), (long)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, step_dev));
   return msc_launch_status();
 }

@@ -71,6 +71,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #ifndef GEMM_NP_W128
 #define GEMM_NP_W128 8      // waves of the multi-workgroup 128x128 tile
 #endif
+#ifndef GEMM_WG_STAGES
+#define GEMM_WG_STAGES 3    // ring depth of the gathered conv weight-gradient kernels (64-byte K steps)
+#endif
 #ifndef GEMM_NT_STORE
 #define GEMM_NT_STORE 1     // output tiles leave with non-temporal stores: written once, never re-read by this launch, so they
 #endif                      // should not evict the operand panels other tiles of the launch still re-read from L2 (-3 % on the linears)
@@ -1026,7 +1029,7 @@ static inline bool can_persist(int amode, int bmode, int dtype) {
 // big = the launch may take the persistent 256x256 kernel: never for launches whose epilogue writes per-row-block side
 // buffers sized by a query (BatchNorm partials, column sums), so those queries depend on (rows, cols) only
 static inline mscplan::Tile tile_for(long M, long N, long zs, int amode, int bmode, int dtype, long K = 0, bool big = false, int bm_cap = 256) {
-  return mscplan::choose_tile(M, N, zs, big && can_persist(amode, bmode, dtype) && zs == 1, num_cus(), K, bm_cap);
+  return mscplan::choose_tile(M, N, zs, big && can_persist(amode, bmode, dtype) && zs == 1, num_cus(), K, bm_cap, bmode == OPM_CONV_WGRAD ? 500 : 0);
 }
 
 extern "C" int64_t msc_conv2d_splitk_workspace_bytes(int64_t rows, int cout, int64_t k_len, int dtype) {
@@ -1066,7 +1069,7 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   // gathered weight gradients (conv wgrad) run best on 64-byte steps x 3 stages x 4 waves (three workgroups per CU);
   // everything else on 128-byte steps x 2 stages, the 128x128 tile with 8 waves
   constexpr bool WG = BMODE == OPM_CONV_WGRAD;
-  constexpr int KBn = WG ? 64 : GEMM_NP_KB, S = WG ? 3 : GEMM_NP_STAGES, W128 = WG ? 256 : 64 * GEMM_NP_W128;
+  constexpr int KBn = WG ? 64 : GEMM_NP_KB, S = WG ? GEMM_WG_STAGES : GEMM_NP_STAGES, W128 = WG ? 256 : 64 * GEMM_NP_W128;
   if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX, KBn, S, false, W128>), grid, dim3(W128), 0, st, p);
   else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, p);
   else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, p);

@@ -60,7 +60,10 @@ static inline bool forced_tile(Tile& t) {
 // allow256: the launch may use the PERSISTENT 256-row kernels (bf16, both operands k-major, zs == 1): one 8-wave workgroup
 // per CU walks the tiles with the next tile's first K steps in flight under the current epilogue.  They are taken when the
 // tile count fills the CUs evenly enough: `waste` = idle share of the last round of ceil(tiles / CUs) rounds.
-static inline Tile choose_tile(long M, long N, long zs, bool allow256, long ncu = 256, long K = 0, int bm_cap = 256) {
+// min_wgs: workgroups (tiles x zs) below which the tile shrinks to 64-wide: 200 for the forward / dgrad launches (tuned in the
+// step), 500 for the gathered conv weight gradients, whose K slices are capped by the reduction length (sweep: the best tile of
+// every ResNet layer is the one that gives ~860 workgroups).
+static inline Tile choose_tile(long M, long N, long zs, bool allow256, long ncu = 256, long K = 0, int bm_cap = 256, long min_wgs = 0) {
   Tile t;
   t.bm = M <= 64 ? 64 : 128;
   t.bn = N <= 64 ? 64 : 128;
@@ -69,7 +72,8 @@ static inline Tile choose_tile(long M, long N, long zs, bool allow256, long ncu 
   if (forced_tile(f)) {
     if ((f.bm < 256 || allow256) && f.bm <= bm_cap) return f;
   }
-  static const long T128 = getenv("MSC_GEMM_T128") ? atol(getenv("MSC_GEMM_T128")) : 200;   // below: shrink to 64-wide
+  static const long T128env = getenv("MSC_GEMM_T128") ? atol(getenv("MSC_GEMM_T128")) : 0;   // A/B knob
+  const long T128 = T128env ? T128env : (min_wgs ? min_wgs : 200);                            // below: shrink to 64-wide
   // The persistent 256x256 kernel pays only on LARGE contractions (measured, tools/gemm_sweep.py / gemm_big.py): at this
   // path's short K and 1-4 tiles per CU the per-CU store throughput (~8 B/clk) makes every epilogue as long as the K loop
   // and all workgroups hit it together; several smaller workgroups per CU overlap those phases better.

@@ -446,11 +446,11 @@ class MeanPool(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ channel
 class ChannelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rt, snr_db, noise, fading, mode, seed, draw_dev=None):
+    def forward(ctx, x, rt, snr_db, noise, fading, mode, seed, draw=0, draw_dev=None):
         B, k = x.shape
         y = rt.empty(B, k)
         scale = rt.f32(B)
-        rt.call("msc_channel_fwd", x, noise, fading, snr_db, y, scale, B, k, mode, int(seed), draw_dev, rt.dt)
+        rt.call("msc_channel_fwd", x, noise, fading, snr_db, y, scale, B, k, mode, int(seed), int(draw), draw_dev, rt.dt)
         ctx.save_for_backward(x, scale)
         ctx.rt = rt
         return y
@@ -461,7 +461,7 @@ class ChannelFn(torch.autograd.Function):
         rt = ctx.rt
         dx = torch.empty_like(x)
         rt.call("msc_channel_bwd", dy.contiguous(), x, scale, dx, x.shape[0], x.shape[1], rt.dt)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ LiDAR pillars

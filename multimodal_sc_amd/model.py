@@ -149,7 +149,8 @@ class MultimodalSC:
         # and no two DP ranks see the same noise realisation; Trainer sets channel_rank from torch.distributed
         self.channel_seed = 0
         self.channel_rank = 0
-        self.draw_dev = torch.zeros(1, dtype=torch.int64, device=self.rt.device)
+        self.draw_dev = torch.zeros(1, dtype=torch.int64, device=self.rt.device)   # used when rt.host_counters is off (hipGraph)
+        self._draw_host = 0                                                        # forwards so far (eager launches)
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -317,9 +318,14 @@ class MultimodalSC:
         sym = self._lin(self._lin(f, "semantic_encoder.fc1", L.ACT_RELU), "semantic_encoder.fc2")
         mode = L.CH_AWGN if cfg.channel == "awgn" else L.CH_RAYLEIGH
         key = ((self.channel_rank & 0xFFFFFFFF) << 32) | (self.channel_seed & 0xFFFFFFFF)
-        rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, key, self.draw_dev)
-        if noise is None or (mode == L.CH_RAYLEIGH and fading is None):
-            rt.call("msc_counter_add", self.draw_dev, 1)      # the next forward draws fresh noise (also under hipGraph replay)
+        inkernel = noise is None or (mode == L.CH_RAYLEIGH and fading is None)
+        if rt.host_counters:       # eager launches: the draw number is a host argument (no counter kernel on the chain)
+            rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, key, self._draw_host, None)
+            self._draw_host += int(inkernel)
+        else:                      # hipGraph replay: the number must live on the device
+            rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, key, 0, self.draw_dev)
+            if inkernel:
+                rt.call("msc_counter_add", self.draw_dev, 1)
         z = self._lin(self._lin(rx, "semantic_decoder.fc1", L.ACT_RELU), "semantic_decoder.fc2")
         head = self._lin(self._lin(z, "head.fc", L.ACT_TANH), "head.out")
         g = cfg.recon_grid

@@ -44,6 +44,8 @@ class Runtime:
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
+        self.host_counters = True    # step / noise-draw numbers as host arguments; Trainer turns it off for hipGraph replay,
+                                     # where they must be device-side counters (one tiny kernel each per step)
         self.taps = None             # dict -> conv_bn_fwd records the post-ReLU output of every conv+BN+ReLU by weight name (tests)
         self.fused_attention = True  # bf16: flash-style kernel; False forces the batched-GEMM + softmax path (tests)
         self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
@@ -218,9 +220,13 @@ class ParamStore:
         stream before the fusion reads them.  Not used while a hipGraph is being captured or in the instrumented pass."""
         rt = self.rt
         self.step_count += 1
-        rt.call("msc_counter_add", self.step_dev, 1)          # the kernels read the step from device memory, so the
-        hp = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, self.step_dev,
-              float(grad_scale), rt.dt)                         # same launches replay correctly from a hipGraph
+        if rt.host_counters:
+            hp = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.step_count, None,
+                  float(grad_scale), rt.dt)
+        else:
+            rt.call("msc_counter_add", self.step_dev, 1)      # the kernels read the step from device memory, so the
+            hp = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, self.step_dev,
+                  float(grad_scale), rt.dt)                     # same launches replay correctly from a hipGraph
         split = overlap_from if (overlap_from and rt.wgrad_on_side and rt.profile is None
                                  and not torch.cuda.is_current_stream_capturing()) else None
         if not split:

@@ -119,6 +119,8 @@ class Trainer:
         self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
         self.split = model.params.refs["fusion.pos_embed"].off
         self.use_graph = os.environ.get("MSC_HIP_GRAPH", "0") == "1"
+        if self.use_graph:
+            model.rt.host_counters = False     # a replayed launch sequence needs its step / noise-draw numbers on the device
         self.dp_pieces = int(os.environ.get("MSC_DP_PIECES", "3"))    # 2: upper + encoders; 3: upper + mid + rest of the trunk
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
         self.exchange = None      # GradExchange, built on the first multi-rank step (needs the model's mid offset)

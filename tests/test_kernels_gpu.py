@@ -474,7 +474,7 @@ def test_channel(rts, dtype, mode):
     xq = q(x, dtype).requires_grad_()
     ref = Channel(mode)(xq, snr, n, hfad)
     xd = dev(x, rt).requires_grad_()
-    y = F.ChannelFn.apply(xd, rt, snr.to(rt.device), n.to(rt.device), hfad.to(rt.device), L.CH_AWGN if mode == "awgn" else L.CH_RAYLEIGH, 0, None)
+    y = F.ChannelFn.apply(xd, rt, snr.to(rt.device), n.to(rt.device), hfad.to(rt.device), L.CH_AWGN if mode == "awgn" else L.CH_RAYLEIGH, 0, 0, None)
     # Rayleigh deep fades amplify noise by 1/|h|^2: compare relative to the output magnitude
     check("y", y, ref, tol(dtype))
     dy = rnd(B, k, seed=4)
@@ -492,7 +492,7 @@ def test_channel_power_and_snr(rts):
     for snr_db in (-5.0, 0.0, 10.0):
         snr = torch.full((B,), snr_db, device=rt.device)
         y, scale = rt.f32(B, k), rt.f32(B)
-        rt.call("msc_channel_fwd", x, None, None, snr, y, scale, B, k, L.CH_AWGN, 1234, None, rt.dt)
+        rt.call("msc_channel_fwd", x, None, None, snr, y, scale, B, k, L.CH_AWGN, 1234, 0, None, rt.dt)
         s = x * scale[:, None]
         assert abs(float(s.pow(2).mean()) - 1.0) < 1e-5
         meas = 10 * math.log10(1.0 / float((y - s).pow(2).mean()))
@@ -535,9 +535,9 @@ def test_channel_noise_fresh_per_forward_and_per_rank(rts):
     snr = torch.full((B,), 5.0, device=rt.device)
     draw = torch.zeros(1, dtype=torch.int64, device=rt.device)
 
-    def run(seed):
+    def run(seed, hdraw=0):
         y, scale = rt.f32(B, k), rt.f32(B)
-        rt.call("msc_channel_fwd", x, None, None, snr, y, scale, B, k, L.CH_RAYLEIGH, seed, draw, rt.dt)
+        rt.call("msc_channel_fwd", x, None, None, snr, y, scale, B, k, L.CH_RAYLEIGH, seed, hdraw, draw, rt.dt)
         return y
 
     a0 = run(3)
@@ -547,7 +547,9 @@ def test_channel_noise_fresh_per_forward_and_per_rank(rts):
     draw.zero_()
     b0 = run(3)
     torch.cuda.synchronize()
-    assert torch.equal(a0, b0)
+    h1 = run(3, hdraw=1)                     # host-supplied draw 1 + device counter 0 == device counter 1
+    torch.cuda.synchronize()
+    assert torch.equal(a0, b0) and torch.equal(h1, a1)
     assert not torch.equal(a0, a1) and not torch.equal(a1, r1)
     assert (a0 - a1).abs().mean() > 0.1
 
@@ -874,7 +876,7 @@ def test_full_size_invariants_c3_batch64(rts):
     sym = torch.randn(B, k, generator=g).to(torch.bfloat16).to(dev_) * 3
     yc, sc = rt.empty(B, k), torch.empty(B, device=dev_)
     snr = torch.full((B,), 200.0, device=dev_)
-    rt.call("msc_channel_fwd", sym, None, None, snr, yc, sc, B, k, L.CH_AWGN, 7, None, rt.dt)
+    rt.call("msc_channel_fwd", sym, None, None, snr, yc, sc, B, k, L.CH_AWGN, 7, 0, None, rt.dt)
     torch.cuda.synchronize()
     pw = yc.float().pow(2).mean(1)
     assert (pw - 1).abs().max() < 1e-2
