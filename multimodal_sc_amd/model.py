@@ -280,6 +280,13 @@ class MultimodalSC:
             return F.LinearFP8.apply(x, self.rt, P[f"{name}.weight"], P[f"{name}.bias"], act, True)
         return F.Linear.apply(x, None, self.rt, P[f"{name}.weight"], P[f"{name}.bias"], act, True)
 
+    def _mlp2(self, x, n1, act1, n2, act2):
+        """two dense layers as one autograd node (functional.MLP2); the e4m3 codec keeps its per-layer nodes"""
+        P = self.params
+        if (self.cfg.codec_fp8 and n1.startswith("semantic_")) or os.environ.get("MSC_MLP2", "1") == "0":   # (A/B knob)
+            return self._lin(self._lin(x, n1, act1), n2, act2)
+        return F.MLP2.apply(x, self.rt, P[f"{n1}.weight"], P[f"{n1}.bias"], act1, P[f"{n2}.weight"], P[f"{n2}.bias"], act2)
+
     # ------------------------------------------------------------------ forward
     def forward(self, image, points=None, state=None, snr_db=None, noise=None, fading=None):
         """Inputs are fp32 device tensors.  noise/fading None -> in-kernel Philox (throughput mode).
@@ -315,7 +322,7 @@ class MultimodalSC:
         rt.join_side()     # a side-stream Adam update of the transformer / codec / head parameters (Trainer) must have landed
         x = self.fusion(img_tok, bev_tok, st_tok)
         f = F.MeanPool.apply(x, rt)
-        sym = self._lin(self._lin(f, "semantic_encoder.fc1", L.ACT_RELU), "semantic_encoder.fc2")
+        sym = self._mlp2(f, "semantic_encoder.fc1", L.ACT_RELU, "semantic_encoder.fc2", L.ACT_NONE)
         mode = L.CH_AWGN if cfg.channel == "awgn" else L.CH_RAYLEIGH
         key = ((self.channel_rank & 0xFFFFFFFF) << 32) | (self.channel_seed & 0xFFFFFFFF)
         inkernel = noise is None or (mode == L.CH_RAYLEIGH and fading is None)
@@ -326,8 +333,8 @@ class MultimodalSC:
             rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, key, 0, self.draw_dev)
             if inkernel:
                 rt.call("msc_counter_add", self.draw_dev, 1)
-        z = self._lin(self._lin(rx, "semantic_decoder.fc1", L.ACT_RELU), "semantic_decoder.fc2")
-        head = self._lin(self._lin(z, "head.fc", L.ACT_TANH), "head.out")
+        z = self._mlp2(rx, "semantic_decoder.fc1", L.ACT_RELU, "semantic_decoder.fc2", L.ACT_NONE)
+        head = self._mlp2(z, "head.fc", L.ACT_TANH, "head.out", L.ACT_NONE)
         g = cfg.recon_grid
         r1 = self._lin(z, "recon.fc1", L.ACT_RELU).view(B * g * g, cfg.recon_hidden)
         patches = self._lin(r1, "recon.fc2", L.ACT_SIGMOID)
