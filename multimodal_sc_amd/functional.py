@@ -225,6 +225,31 @@ class Linear(torch.autograd.Function):
         return (dx.view(shp) if dx is not None else None), None, None, None, None, None, None
 
 
+class MLP2(torch.autograd.Function):
+    """Two dense layers with an activation in between as ONE autograd node: y = act2(W2 act1(W1 x + b1) + b2).
+    The backward of act1 rides in the epilogue of layer 2's dgrad GEMM (prev_act), so the pair costs no activation-backward
+    launch; used for the codec / head pairs, whose 64-row kernels are launch-latency-bound."""
+
+    @staticmethod
+    def forward(ctx, x, rt, w1, b1, act1, w2, b2, act2):
+        x2d = x.reshape(-1, x.shape[-1])
+        h, hpre = linear_fwd(rt, x2d, w1, b1, act1, None, want_pre=(act1 == L.ACT_GELU))
+        y, ypre = linear_fwd(rt, h, w2, b2, act2, None, want_pre=(act2 == L.ACT_GELU))
+        ctx.save_for_backward(x2d, h, hpre if act1 == L.ACT_GELU else None, ypre if act2 == L.ACT_GELU else (y if act2 != L.ACT_NONE else None))
+        ctx.cfg = (rt, w1, b1, act1, w2, b2, act2, x.shape)
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, h, hpre, yref = ctx.saved_tensors
+        rt, w1, b1, act1, w2, b2, act2, shp = ctx.cfg
+        dy2d = dy.reshape(-1, dy.shape[-1]).contiguous()
+        ref1 = hpre if act1 == L.ACT_GELU else h
+        dh = linear_bwd(rt, dy2d, h, yref, w2, b2, act2, prev_act=act1, prev_ref=ref1 if act1 != L.ACT_NONE else None)
+        dx = linear_bwd(rt, dh, x2d, None, w1, b1, L.ACT_NONE)
+        return dx.view(shp), None, None, None, None, None, None, None
+
+
 class LinearFP8(torch.autograd.Function):
     """Semantic encoder / decoder GEMM on OCP e4m3 operands (BASELINE.json configs[4]); oracle: oracle.model.FP8Linear.
     Forward: per-tensor quantise x (activations) and W (fp32 master), contraction on the fp8 MFMA, fused bias + activation.
