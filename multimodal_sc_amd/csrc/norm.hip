@@ -7,6 +7,12 @@
 #include "msc_common.h"
 
 #define BN_MAX_BLOCKS 1024
+#ifndef BN_UN
+#define BN_UN 1      // rows per thread in flight in the BatchNorm-backward reduction (4: faster alone, no gain inside the step)
+#endif
+#ifndef LN_UR
+#define LN_UR 1      // rows per wave in flight in the LayerNorm backward (2: no gain inside the step)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Finalize of every two-stat column reduction: partial [nblk][2][C] -> sums over blocks.
@@ -118,34 +124,64 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
 }
 
 // Stage 1 of BN backward: per-block partial sums of dz and dz*xhat over a slab of rows.
-// Threads: tx = channel chunk (C/VEC of them), ty = row lane.
+// Threads: tx = channel chunk (C/VEC of them), ty = row lane.  Four rows per thread are in flight at a time (the loop is
+// latency-bound otherwise: one 16-B load per operand per iteration left the kernel at ~2 TB/s).
+// scale != nullptr: the ReLU mask is rebuilt as x*scale+shift > 0 (the forward's folded affine; valid when the forward had no
+// residual input) and y is not read.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ partial,
+                                                            const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ partial,
                                                             long rows, int C, int relu, int rows_per_block) {
   constexpr int VEC = msc_traits<T>::VEC;
+  constexpr int UN = BN_UN;
   const int ncx = C / VEC;          // threads across channels
   const int nty = 256 / ncx;        // rows handled concurrently
   const int tx = threadIdx.x % ncx, ty = threadIdx.x / ncx;
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
-  float s1[VEC], s2[VEC], mu[VEC], rs[VEC];
+  const bool xmask = relu && scale != nullptr;
+  const bool ymask = relu && scale == nullptr;
+  float s1[VEC], s2[VEC], mu[VEC], rs[VEC], sc[VEC], sh[VEC];
   ldc<VEC>(mean + tx * VEC, mu);
   ldc<VEC>(rstd + tx * VEC, rs);
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; sc[j] = 0.f; sh[j] = 0.f; }
+  if (xmask) { ldc<VEC>(scale + tx * VEC, sc); ldc<VEC>(shift + tx * VEC, sh); }
   if (ty < nty) {
-    for (long r = r0 + ty; r < r1; r += nty) {
+    long r = r0 + ty;
+    for (; r + (long)(UN - 1) * nty < r1; r += (long)UN * nty) {
+      vecf<T> vd[UN], vx[UN], vy[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const long e = (r + (long)u * nty) * C + tx * VEC;
+        vd[u].load(dy + e);
+        vx[u].load(x + e);
+        if (ymask) vy[u].load(y + e);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float dz = vd[u].v[j];
+          if (ymask && !(vy[u].v[j] > 0.f)) dz = 0.f;
+          if (xmask && !(fmaf(vx[u].v[j], sc[j], sh[j]) > 0.f)) dz = 0.f;
+          s1[j] += dz;
+          s2[j] += dz * (vx[u].v[j] - mu[j]) * rs[j];
+        }
+    }
+    for (; r < r1; r += nty) {
       const long e = r * C + tx * VEC;
       vecf<T> vd, vx, vy;
       vd.load(dy + e);
       vx.load(x + e);
-      if (relu) vy.load(y + e);
+      if (ymask) vy.load(y + e);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         float dz = vd.v[j];
-        if (relu && !(vy.v[j] > 0.f)) dz = 0.f;
+        if (ymask && !(vy.v[j] > 0.f)) dz = 0.f;
+        if (xmask && !(fmaf(vx.v[j], sc[j], sh[j]) > 0.f)) dz = 0.f;
         s1[j] += dz;
         s2[j] += dz * (vx.v[j] - mu[j]) * rs[j];
       }
@@ -167,37 +203,215 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// Stage 3: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M); dres = dz (optional)
+// Stage 3: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M); dres = dz (optional).  scale != nullptr: mask from x (see stage 1)
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ sum_dz,
+                                    const float* __restrict__ gamma, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ sum_dz,
                                     const float* __restrict__ sum_dzx, T* __restrict__ dx, T* __restrict__ dres,
                                     long nvec, int C, int relu, float inv_rows) {
   constexpr int VEC = msc_traits<T>::VEC;
+  const bool xmask = relu && scale != nullptr;
+  const bool ymask = relu && scale == nullptr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
     const long e = i * VEC;
     const int c0 = (int)(e % C);
     vecf<T> vd, vx, vy, vo;
     vd.load(dy + e);
     vx.load(x + e);
-    if (relu) vy.load(y + e);
-    float mu[VEC], rs[VEC], ga[VEC], sa[VEC], sb[VEC];
+    if (ymask) vy.load(y + e);
+    float mu[VEC], rs[VEC], ga[VEC], sa[VEC], sb[VEC], sc[VEC], sh[VEC];
     ldc<VEC>(mean + c0, mu);
     ldc<VEC>(rstd + c0, rs);
     ldc<VEC>(gamma + c0, ga);
     ldc<VEC>(sum_dz + c0, sa);
     ldc<VEC>(sum_dzx + c0, sb);
+    if (xmask) { ldc<VEC>(scale + c0, sc); ldc<VEC>(shift + c0, sh); }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float dz = vd.v[j];
-      if (relu && !(vy.v[j] > 0.f)) dz = 0.f;
+      if (ymask && !(vy.v[j] > 0.f)) dz = 0.f;
+      if (xmask && !(fmaf(vx.v[j], sc[j], sh[j]) > 0.f)) dz = 0.f;
       const float xh = (vx.v[j] - mu[j]) * rs[j];
       vo.v[j] = ga[j] * rs[j] * (dz - sa[j] * inv_rows - xh * sb[j] * inv_rows);
       vd.v[j] = dz;
     }
     vo.store(dx + e);
     if (dres) vd.store(dres + e);
+  }
+}
+
+// ---------------------------------------------------------------- stem: BatchNorm + ReLU + max-pool fused
+// ImageEncoder stem (conv 7x7/2 -> BN -> ReLU -> max-pool 3x3/2): the post-activation map (103 MB at 64 frames) is never
+// written.  Forward: one pass reads the conv output, normalises, clamps, rounds to the storage type (so values and tie-breaks
+// equal the unfused kernels bit for bit) and writes the pooled map + the arg-max tap ids.  Backward: the BatchNorm-backward
+// passes GATHER their incoming gradient from the pooled gradient through the tap ids (what maxpool_bwd would have written out
+// and they would have read back) and rebuild the ReLU mask from x*scale+shift > 0 — 412 MB less traffic and two launches
+// fewer per step.
+struct PoolGeo { int H, W, Ho, Wo, K, S, P; };
+
+template <typename T> __device__ __forceinline__ float round_store(float v) { return v; }
+template <> __device__ __forceinline__ float round_store<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+template <typename T>
+__global__ void bn_relu_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                        T* __restrict__ y, uint8_t* __restrict__ idx, int B, int C, PoolGeo g) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int cv = C / VEC;
+  const long n = (long)B * g.Ho * g.Wo * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned iu = (unsigned)i;   // n < 2^31 (launcher)
+    const int c0 = (int)(iu % (unsigned)cv) * VEC;
+    unsigned t = iu / (unsigned)cv;
+    const int wo = (int)(t % (unsigned)g.Wo); t /= (unsigned)g.Wo;
+    const int ho = (int)(t % (unsigned)g.Ho);
+    const int b = (int)(t / (unsigned)g.Ho);
+    float sc[VEC], sh[VEC], best[VEC];
+    int bi[VEC];
+    ldc<VEC>(scale + c0, sc);
+    ldc<VEC>(shift + c0, sh);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int kh = 0; kh < g.K; ++kh) {
+      const int hi = ho * g.S - g.P + kh;
+      if ((unsigned)hi >= (unsigned)g.H) continue;
+      for (int kw = 0; kw < g.K; ++kw) {
+        const int wi = wo * g.S - g.P + kw;
+        if ((unsigned)wi >= (unsigned)g.W) continue;
+        vecf<T> v;
+        v.load(x + (((long)b * g.H + hi) * g.W + wi) * C + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float a = fmaf(v.v[j], sc[j], sh[j]);
+          a = round_store<T>(a > 0.f ? a : 0.f);                 // the value bn_apply would have stored
+          if (a > best[j]) { best[j] = a; bi[j] = kh * g.K + kw; }
+        }
+      }
+    }
+    vecf<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
+    const long oo = (((long)b * g.Ho + ho) * g.Wo + wo) * C + c0;
+    o.store(y + oo);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) idx[oo + j] = (uint8_t)bi[j];
+  }
+}
+
+// gradient w.r.t. the pre-pool pixel (b,h,w), channels c0..c0+VEC-1: sum of the pooled gradients of the windows whose arg-max it is
+template <typename T>
+__device__ __forceinline__ void pool_gather(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, int b, int h, int w, int C, int c0,
+                                            const PoolGeo& g, float (&acc)[msc_traits<T>::VEC]) {
+  constexpr int VEC = msc_traits<T>::VEC;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  // windows (ho, kh) that contain row h: h = ho*S - P + kh  ->  kh = (h+P) mod S, +S, ...  (at most ceil(K/S) per axis)
+  const int hq = h + g.P, wq = w + g.P;
+  for (int kh = hq % g.S, ho = hq / g.S; kh < g.K && ho >= 0; kh += g.S, --ho) {
+    if (ho >= g.Ho) continue;
+    for (int kw = wq % g.S, wo = wq / g.S; kw < g.K && wo >= 0; kw += g.S, --wo) {
+      if (wo >= g.Wo) continue;
+      const long oo = (((long)b * g.Ho + ho) * g.Wo + wo) * C + c0;
+      vecf<T> gr;
+      gr.load(dpool + oo);
+      uint64_t taps;
+      if constexpr (VEC == 8) taps = *reinterpret_cast<const uint64_t*>(idx + oo);
+      else taps = *reinterpret_cast<const uint32_t*>(idx + oo);
+      const unsigned want = (unsigned)(kh * g.K + kw);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (((taps >> (8 * j)) & 0xffu) == want) acc[j] += gr.v[j];
+    }
+  }
+}
+
+// stage 1 (sums of dz and dz*xhat), incoming gradient gathered through the pool, ReLU mask rebuilt from x
+template <typename T>
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                 const T* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ partial, long rows,
+                                                                 int C, int rows_per_block, PoolGeo g) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const int ncx = C / VEC, nty = 256 / ncx;
+  const int tx = threadIdx.x % ncx, ty = threadIdx.x / ncx;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  float s1[VEC], s2[VEC], mu[VEC], rs[VEC], sc[VEC], sh[VEC];
+  ldc<VEC>(mean + tx * VEC, mu);
+  ldc<VEC>(rstd + tx * VEC, rs);
+  ldc<VEC>(scale + tx * VEC, sc);
+  ldc<VEC>(shift + tx * VEC, sh);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (ty < nty) {
+    for (long r = r0 + ty; r < r1; r += nty) {
+      const unsigned ru = (unsigned)r;
+      const int w = (int)(ru % (unsigned)g.W);
+      const unsigned t = ru / (unsigned)g.W;
+      const int h = (int)(t % (unsigned)g.H), b = (int)(t / (unsigned)g.H);
+      float dz[VEC];
+      pool_gather<T>(dpool, idx, b, h, w, C, tx * VEC, g, dz);
+      vecf<T> vx;
+      vx.load(x + r * C + tx * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float d = fmaf(vx.v[j], sc[j], sh[j]) > 0.f ? dz[j] : 0.f;
+        s1[j] += d;
+        s2[j] += d * (vx.v[j] - mu[j]) * rs[j];
+      }
+    }
+  }
+  __shared__ float red[2][2048];
+  float* r1p = &red[0][0];
+  float* r2p = &red[1][0];
+  if (ty < nty) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { r1p[ty * C + tx * VEC + j] = s1[j]; r2p[ty * C + tx * VEC + j] = s2[j]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, bb = 0.f;
+    for (int t = 0; t < nty; ++t) { a += r1p[t * C + c]; bb += r2p[t * C + c]; }
+    partial[(long)blockIdx.x * 2 * C + c] = a;
+    partial[(long)blockIdx.x * 2 * C + C + c] = bb;
+  }
+}
+
+// stage 3: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M)
+template <typename T>
+__global__ void bn_pool_bwd_apply_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                         const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ sum_dz,
+                                         const float* __restrict__ sum_dzx, T* __restrict__ dx, long nvec, int C, float inv_rows, PoolGeo g) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const unsigned cv = (unsigned)(C / VEC);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const unsigned iu = (unsigned)i;   // nvec < 2^31 (launcher)
+    const int c0 = (int)(iu % cv) * VEC;
+    unsigned t = iu / cv;
+    const int w = (int)(t % (unsigned)g.W); t /= (unsigned)g.W;
+    const int h = (int)(t % (unsigned)g.H), b = (int)(t / (unsigned)g.H);
+    float dz[VEC];
+    pool_gather<T>(dpool, idx, b, h, w, C, c0, g, dz);
+    vecf<T> vx, vo;
+    vx.load(x + i * VEC);
+    float mu[VEC], rs[VEC], ga[VEC], sa[VEC], sb[VEC], sc[VEC], sh[VEC];
+    ldc<VEC>(mean + c0, mu);
+    ldc<VEC>(rstd + c0, rs);
+    ldc<VEC>(gamma + c0, ga);
+    ldc<VEC>(sum_dz + c0, sa);
+    ldc<VEC>(sum_dzx + c0, sb);
+    ldc<VEC>(scale + c0, sc);
+    ldc<VEC>(shift + c0, sh);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float d = fmaf(vx.v[j], sc[j], sh[j]) > 0.f ? dz[j] : 0.f;
+      const float xh = (vx.v[j] - mu[j]) * rs[j];
+      vo.v[j] = ga[j] * rs[j] * (d - sa[j] * inv_rows - xh * sb[j] * inv_rows);
+    }
+    vo.store(dx + i * VEC);
   }
 }
 
@@ -271,45 +485,64 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int j = 0; j < VEC; ++j) { dg[it * VEC + j] = 0.f; db[it * VEC + j] = 0.f; ga[it * VEC + j] = g[j]; }
   }
   const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
-  for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 4) {
-    const long row = r0 + rr;
-    if (row >= rows) break;
-    const float mu = mean[row], rs = rstd[row];
-    vecf<T> vd[MAXIT], vx[MAXIT];
-    float s1 = 0.f, s2 = 0.f;
+  // two rows per wave in flight (rows rr and rr+4): the loads of the second row hide the wave-reduce + store of the first
+  constexpr int UR = LN_UR;
+  for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 4 * UR) {
+    if (r0 + rr >= rows) break;
+    vecf<T> vd[UR][MAXIT], vx[UR][MAXIT], va[UR][MAXIT];
+    float mu[UR], rs[UR];
+    bool ok[UR];
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
-      if (it < nit) {
-        const int c0 = (it * 64 + lane) * VEC;
-        vd[it].load(dy + row * D + c0);
-        vx[it].load(x + row * D + c0);
+    for (int u = 0; u < UR; ++u) {
+      const long row = r0 + rr + 4 * u;
+      ok[u] = rr + 4 * u < LN_ROWS_PER_BLOCK && row < rows;
+      if (ok[u]) {
+        mu[u] = mean[row];
+        rs[u] = rstd[row];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const float xh = (vx[it].v[j] - mu) * rs;
-          const float g = vd[it].v[j] * ga[it * VEC + j];
-          vx[it].v[j] = xh;
-          s1 += g;
-          s2 += g * xh;
-          dg[it * VEC + j] += vd[it].v[j] * xh;
-          db[it * VEC + j] += vd[it].v[j];
-        }
+        for (int it = 0; it < MAXIT; ++it)
+          if (it < nit) {
+            const int c0 = (it * 64 + lane) * VEC;
+            vd[u][it].load(dy + row * D + c0);
+            vx[u][it].load(x + row * D + c0);
+            if (dadd) va[u][it].load(dadd + row * D + c0);
+          }
       }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
+    }
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
-      if (it < nit) {
-        const int c0 = (it * 64 + lane) * VEC;
-        vecf<T> va;
-        if (dadd) va.load(dadd + row * D + c0);
+    for (int u = 0; u < UR; ++u) {
+      if (!ok[u]) continue;
+      const long row = r0 + rr + 4 * u;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float o = rs * (vd[it].v[j] * ga[it * VEC + j] - s1 - vx[it].v[j] * s2);
-          if (dadd) o += va.v[j];
-          vx[it].v[j] = o;
+      for (int it = 0; it < MAXIT; ++it)
+        if (it < nit) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float xh = (vx[u][it].v[j] - mu[u]) * rs[u];
+            const float g = vd[u][it].v[j] * ga[it * VEC + j];
+            vx[u][it].v[j] = xh;
+            s1 += g;
+            s2 += g * xh;
+            dg[it * VEC + j] += vd[u][it].v[j] * xh;
+            db[it * VEC + j] += vd[u][it].v[j];
+          }
         }
-        vx[it].store(dx + row * D + c0);
-      }
+      s1 = wave_sum(s1) / (float)D;
+      s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it)
+        if (it < nit) {
+          const int c0 = (it * 64 + lane) * VEC;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float o = rs[u] * (vd[u][it].v[j] * ga[it * VEC + j] - s1 - vx[u][it].v[j] * s2);
+            if (dadd) o += va[u][it].v[j];
+            vx[u][it].v[j] = o;
+          }
+          vx[u][it].store(dx + row * D + c0);
+        }
+    }
   }
   // cross-wave reduce of dgamma/dbeta, then one partial row per block
   __shared__ float red[2][4][1024];
@@ -451,7 +684,7 @@ extern "C" int64_t msc_bn_bwd_workspace_bytes(int C) { return (int64_t)(BN_MAX_B
 
 template <typename T>
 static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
-                    const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, int64_t rows,
+                    const float* gamma, const float* scale, const float* shift, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, int64_t rows,
                     int C, int relu, int accumulate, hipStream_t st) {
   constexpr int VEC = msc_traits<T>::VEC;
   if (C % VEC || C / VEC > 256) return MSC_ERR_BAD_ARG;
@@ -464,23 +697,85 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* m
   float* partial = ws;
   float* sums = ws + (long)BN_MAX_BLOCKS * 2 * C;  // [2][C]
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y,
-                     mean, rstd, partial, (long)rows, C, relu, rpb);
+                     mean, rstd, scale, shift, partial, (long)rows, C, relu, rpb);
   launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
   const long nvec = rows * C / VEC;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dy, (const T*)x,
-                     (const T*)y, mean, rstd, gamma, sums, sums + C, (T*)dx, (T*)dres, nvec, C, relu,
+                     (const T*)y, mean, rstd, gamma, scale, shift, sums, sums + C, (T*)dx, (T*)dres, nvec, C, relu,
                      1.f / (float)rows);
   return msc_launch_status();
 }
 
 extern "C" int msc_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
-                          const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, float* ws,
-                          int64_t rows, int C, int relu, int accumulate, int dtype, void* stream) {
+                          const float* gamma, const float* scale, const float* shift, void* dx, void* dres, float* dgamma,
+                          float* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && rows > 0 && C > 0);
-  MSC_CHECK_ARG(!relu || y);
+  MSC_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+  MSC_CHECK_ARG(!relu || y || scale);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MSC_F32) return bn_bwd_t<float>(dy, x, y, mean, rstd, gamma, dx, dres, dgamma, dbeta, ws, rows, C, relu, accumulate, st);
-  if (dtype == MSC_BF16) return bn_bwd_t<bf16_t>(dy, x, y, mean, rstd, gamma, dx, dres, dgamma, dbeta, ws, rows, C, relu, accumulate, st);
+  if (dtype == MSC_F32)
+    return bn_bwd_t<float>(dy, x, y, mean, rstd, gamma, scale, shift, dx, dres, dgamma, dbeta, ws, rows, C, relu, accumulate, st);
+  if (dtype == MSC_BF16)
+    return bn_bwd_t<bf16_t>(dy, x, y, mean, rstd, gamma, scale, shift, dx, dres, dgamma, dbeta, ws, rows, C, relu, accumulate, st);
+  return MSC_ERR_BAD_ARG;
+}
+
+// ---- stem: BN + ReLU + max-pool fused (see the kernels above).  x: conv output [B,H,W,C]; y/idx: [B,Ho,Wo,C]
+extern "C" int msc_bn_relu_pool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int B, int H, int W,
+                                    int C, int K, int S, int P, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && scale && shift && y && idx && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && K * K <= 255 && S > 0 && P >= 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  PoolGeo g = {H, W, (H + 2 * P - K) / S + 1, (W + 2 * P - K) / S + 1, K, S, P};
+  MSC_CHECK_ARG(g.Ho > 0 && g.Wo > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSC_F32) {
+    MSC_CHECK_ARG(C % 4 == 0 && (long)B * g.Ho * g.Wo * C / 4 < 0x7fffffffL);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, (const float*)x, scale,
+                       shift, (float*)y, idx, B, C, g);
+  } else {
+    MSC_CHECK_ARG(C % 8 == 0 && (long)B * g.Ho * g.Wo * C / 8 < 0x7fffffffL);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16_t>, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 8)), dim3(256), 0, st, (const bf16_t*)x,
+                       scale, shift, (bf16_t*)y, idx, B, C, g);
+  }
+  return msc_launch_status();
+}
+
+template <typename T>
+static int bn_pool_bwd_t(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta, float* ws, int B, int C,
+                         PoolGeo g, int accumulate, hipStream_t st) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  if (C % VEC || C / VEC > 256) return MSC_ERR_BAD_ARG;
+  const int ncx = C / VEC, nty = 256 / ncx;
+  if (nty < 1 || (long)nty * C > 2048) return MSC_ERR_BAD_ARG;
+  const long rows = (long)B * g.H * g.W;
+  if (rows * (C / VEC) >= 0x7fffffffL) return MSC_ERR_UNSUPPORTED;
+  int nblk = cdiv(rows, 128);
+  if (nblk > BN_MAX_BLOCKS) nblk = BN_MAX_BLOCKS;
+  const int rpb = cdiv(rows, nblk);
+  nblk = cdiv(rows, rpb);
+  float* partial = ws;
+  float* sums = ws + (long)BN_MAX_BLOCKS * 2 * C;
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dpool, idx, (const T*)x, mean, rstd, scale, shift,
+                     partial, rows, C, rpb, g);
+  launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
+  const long nvec = rows * C / VEC;
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dpool, idx, (const T*)x, mean, rstd, gamma,
+                     scale, shift, sums, sums + C, (T*)dx, nvec, C, 1.f / (float)rows, g);
+  return msc_launch_status();
+}
+
+// dpool: gradient w.r.t. the pooled map [B,Ho,Wo,C]; dx: gradient w.r.t. the conv output x [B,H,W,C]; ws as msc_bn_bwd
+extern "C" int msc_bn_relu_pool_bwd(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta,
+                                    float* ws, int B, int H, int W, int C, int K, int S, int P, int accumulate, int dtype, void* stream) {
+  MSC_CHECK_ARG(dpool && idx && x && mean && rstd && gamma && scale && shift && dx && dgamma && dbeta && ws);
+  MSC_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && S > 0 && P >= 0);
+  PoolGeo g = {H, W, (H + 2 * P - K) / S + 1, (W + 2 * P - K) / S + 1, K, S, P};
+  MSC_CHECK_ARG(g.Ho > 0 && g.Wo > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSC_F32) return bn_pool_bwd_t<float>(dpool, idx, x, mean, rstd, gamma, scale, shift, dx, dgamma, dbeta, ws, B, C, g, accumulate, st);
+  if (dtype == MSC_BF16) return bn_pool_bwd_t<bf16_t>(dpool, idx, x, mean, rstd, gamma, scale, shift, dx, dgamma, dbeta, ws, B, C, g, accumulate, st);
   return MSC_ERR_BAD_ARG;
 }
 

@@ -43,24 +43,29 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
     rt.call("msc_bn_apply", y_raw, stats[2], stats[3], res, y, M, Cout, int(relu), rt.dt)
     if rt.taps is not None and relu:
         rt.taps[conv.name] = y
-    return y, y_raw, mean, rstd
+    return y, y_raw, stats
 
 
 _STEM_WGRAD_MAIN = os.environ.get("MSC_STEM_WGRAD_MAIN", "1") != "0"
+_MASK_FROM_X = os.environ.get("MSC_BN_MASK_FROM_X", "1") != "0"   # A/B knob: 0 = BatchNorm backward reads y for every ReLU mask
+_FUSED_STEM = os.environ.get("MSC_FUSED_STEM", "1") != "0"    # A/B knob: 0 = separate bn_apply / max-pool kernels in the stem
 _FUSED_BIAS = os.environ.get("MSC_FUSED_BIAS", "1") != "0"    # A/B knob: 0 = bias gradients by separate column-sum launches
 
 
-def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, mean, rstd, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad,
-                relu, want_dres, need_dx, dx_res=None):
-    """-> (dx or None, dres or None).  dx_res: extra gradient w.r.t. x added inside the dgrad epilogue."""
+def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad,
+                relu, want_dres, need_dx, dx_res=None, had_res=False):
+    """-> (dx or None, dres or None).  dx_res: extra gradient w.r.t. x added inside the dgrad epilogue.
+    stats: [4,C] mean, rstd, scale, shift of the forward.  had_res: the forward added a residual before the ReLU (the mask
+    then has to come from y; otherwise it is rebuilt from y_raw*scale+shift and y is not read)."""
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = conv.shape
     M = y_raw.numel() // Cout
     d_raw = torch.empty_like(y_raw)
     dres = torch.empty_like(y_raw) if want_dres else None
     ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
-    rt.call("msc_bn_bwd", dy, y_raw, y, mean, rstd, gamma.p, d_raw, dres, gamma.g, beta.g, ws, M, Cout, int(relu),
-            rt.accumulate, rt.dt)
+    xmask = relu and not had_res and _MASK_FROM_X
+    rt.call("msc_bn_bwd", dy, y_raw, y, stats[0], stats[1], gamma.p, stats[2] if xmask else None, stats[3] if xmask else None,
+            d_raw, dres, gamma.g, beta.g, ws, M, Cout, int(relu), rt.accumulate, rt.dt)
     wsb = L.query("msc_wgrad_workspace_bytes", Cout, KH * KW * Cin, M)
     wsw = rt.workspace("wgrad", wsb, per_stream=False)     # only the side stream touches it
     def wgrad():
@@ -87,17 +92,70 @@ class ConvBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, rt, conv, gamma, beta, stride, pad, relu, need_dx):
         # anchor: any tensor with requires_grad=True; keeps this node in the graph when x needs no gradient
-        y, y_raw, mean, rstd = conv_bn_fwd(rt, x, None, conv, gamma, beta, stride, pad, relu)
-        ctx.save_for_backward(x, y_raw, y, mean, rstd)
+        y, y_raw, stats = conv_bn_fwd(rt, x, None, conv, gamma, beta, stride, pad, relu)
+        ctx.save_for_backward(x, y_raw, y, stats)
         ctx.cfg = (rt, conv, gamma, beta, stride, pad, relu, need_dx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y_raw, y, mean, rstd = ctx.saved_tensors
+        x, y_raw, y, stats = ctx.saved_tensors
         rt, conv, gamma, beta, stride, pad, relu, need_dx = ctx.cfg
-        dx, _ = conv_bn_bwd(rt, dy.contiguous(), x, y_raw, y, mean, rstd, conv, gamma, beta, stride, pad, relu, False, need_dx)
+        dx, _ = conv_bn_bwd(rt, dy.contiguous(), x, y_raw, y, stats, conv, gamma, beta, stride, pad, relu, False, need_dx)
         return (dx,) + (None,) * 9
+
+
+class StemFn(torch.autograd.Function):
+    """ImageEncoder stem as ONE autograd node: conv (implicit GEMM + fused BN statistics) -> BN finalize -> BN + ReLU + max-pool
+    in one pass (msc_bn_relu_pool_fwd).  The post-activation map (103 MB at 64 frames) is never written; the backward gathers
+    the pooled gradient through the arg-max ids and rebuilds the ReLU mask from the conv output (msc_bn_relu_pool_bwd), then
+    runs the weight gradient.  The stem's input is the image: no data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, rt, conv, gamma, beta, stride, pad, pK, pS, pP):
+        B, H, W, Cin = x.shape
+        Cout, KH, KW, _ = conv.shape
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        M = B * Ho * Wo
+        nblk = L.query("msc_conv2d_fwd_stat_rows", M, Cout, rt.dt)
+        y_raw = rt.empty(B, Ho, Wo, Cout)
+        partial = rt.workspace("bn_partial", nblk * 2 * Cout * 4)
+        wsb = L.query("msc_conv2d_splitk_workspace_bytes", M, Cout, KH * KW * Cin, rt.dt)
+        ws = rt.workspace("conv_splitk", wsb) if wsb else None
+        rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsb, rt.dt)
+        stats = rt.f32(4, Cout)
+        rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, gamma.p, beta.p, stats[0], stats[1], stats[2], stats[3])
+        Hp, Wp = (Ho + 2 * pP - pK) // pS + 1, (Wo + 2 * pP - pK) // pS + 1
+        y = rt.empty(B, Hp, Wp, Cout)
+        idx = torch.empty(B, Hp, Wp, Cout, dtype=torch.uint8, device=x.device)
+        rt.call("msc_bn_relu_pool_fwd", y_raw, stats[2], stats[3], y, idx, B, Ho, Wo, Cout, pK, pS, pP, rt.dt)
+        if rt.taps is not None:   # parity tests compare ReLU masks: materialise the activation the fused pass never stores
+            act = rt.empty(B, Ho, Wo, Cout)
+            rt.call("msc_bn_apply", y_raw, stats[2], stats[3], None, act, M, Cout, 1, rt.dt)
+            rt.taps[conv.name] = act
+        ctx.save_for_backward(x, y_raw, stats, idx)
+        ctx.cfg = (rt, conv, gamma, beta, stride, pad, pK, pS, pP)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y_raw, stats, idx = ctx.saved_tensors
+        rt, conv, gamma, beta, stride, pad, pK, pS, pP = ctx.cfg
+        B, H, W, Cin = x.shape
+        Cout, KH, KW, _ = conv.shape
+        _, Ho, Wo, _ = y_raw.shape
+        d_raw = torch.empty_like(y_raw)
+        ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
+        rt.call("msc_bn_relu_pool_bwd", dy.contiguous(), idx, y_raw, stats[0], stats[1], gamma.p, stats[2], stats[3], d_raw, gamma.g, beta.g,
+                ws, B, Ho, Wo, Cout, pK, pS, pP, rt.accumulate, rt.dt)
+        wsb = L.query("msc_wgrad_workspace_bytes", Cout, KH * KW * Cin, B * Ho * Wo)
+        if _STEM_WGRAD_MAIN:     # last node of the backward: nothing left on the launching stream to hide behind (see conv_bn_bwd)
+            rt.call("msc_conv2d_wgrad", x, d_raw, conv.g, rt.workspace("wgrad_main", wsb), wsb, B, H, W, Cin, Cout, KH, KW, stride, pad,
+                    rt.accumulate, rt.dt)
+        else:
+            rt.call_side("msc_conv2d_wgrad", x, d_raw, conv.g, rt.workspace("wgrad", wsb, per_stream=False), wsb, B, H, W, Cin, Cout, KH, KW,
+                         stride, pad, rt.accumulate, rt.dt)
+        return (None,) * 11
 
 
 class BasicBlockFn(torch.autograd.Function):
@@ -106,16 +164,16 @@ class BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rt, p, stride):
         # p: dict of ParamRefs: conv1,bn1g,bn1b,conv2,bn2g,bn2b[,dconv,dbng,dbnb]
-        o1, o1_raw, m1, r1 = conv_bn_fwd(rt, x, None, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True)
+        o1, o1_raw, st1 = conv_bn_fwd(rt, x, None, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True)
         has_ds = "dconv" in p
         if has_ds:
-            idt, idt_raw, md, rd = conv_bn_fwd(rt, x, None, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False)
+            idt, idt_raw, std = conv_bn_fwd(rt, x, None, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False)
         else:
             idt = x
-        y, o2_raw, m2, r2 = conv_bn_fwd(rt, o1, idt, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True)
-        saved = [x, o1_raw, o1, m1, r1, o2_raw, y, m2, r2]
+        y, o2_raw, st2 = conv_bn_fwd(rt, o1, idt, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True)
+        saved = [x, o1_raw, o1, st1, o2_raw, y, st2]
         if has_ds:
-            saved += [idt_raw, md, rd]
+            saved += [idt_raw, std]
         ctx.save_for_backward(*saved)
         ctx.cfg = (rt, p, stride, has_ds)
         return y
@@ -124,15 +182,16 @@ class BasicBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         rt, p, stride, has_ds = ctx.cfg
         sv = ctx.saved_tensors
-        x, o1_raw, o1, m1, r1, o2_raw, y, m2, r2 = sv[:9]
-        # conv2/bn2: dres = gradient of the identity branch (post-ReLU mask)
-        do1, didt = conv_bn_bwd(rt, dy.contiguous(), o1, o2_raw, y, m2, r2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True, True, True)
+        x, o1_raw, o1, st1, o2_raw, y, st2 = sv[:7]
+        # conv2/bn2: dres = gradient of the identity branch (post-ReLU mask, which needs y: the residual was added before the ReLU)
+        do1, didt = conv_bn_bwd(rt, dy.contiguous(), o1, o2_raw, y, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True, True, True,
+                                had_res=True)
         if has_ds:
-            idt_raw, md, rd = sv[9:]
-            dx_id, _ = conv_bn_bwd(rt, didt, x, idt_raw, None, md, rd, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False, False, True)
+            idt_raw, std = sv[7:]
+            dx_id, _ = conv_bn_bwd(rt, didt, x, idt_raw, None, std, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False, False, True)
         else:
             dx_id = didt
-        dx, _ = conv_bn_bwd(rt, do1, x, o1_raw, o1, m1, r1, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True, False, True, dx_res=dx_id)
+        dx, _ = conv_bn_bwd(rt, do1, x, o1_raw, o1, st1, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True, False, True, dx_res=dx_id)
         return dx, None, None, None
 
 

@@ -230,9 +230,14 @@ class MultimodalSC:
         B, C, H, W = image.shape
         x = rt.empty(B, H, W, IMG_CPAD)
         rt.call("msc_image_to_nhwc", image, x, B, C, H, W, IMG_CPAD, rt.dt)
-        x = F.ConvBNAct.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
-                              P["image_encoder.bn1.bias"], 2, 3, True, False)
-        x = F.MaxPool.apply(x, rt, 3, 2, 1)
+        if F._FUSED_STEM:
+            # conv -> BN -> ReLU -> max-pool with the BN/ReLU/pool part in one pass (the post-activation map is never written)
+            x = F.StemFn.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
+                               P["image_encoder.bn1.bias"], 2, 3, 3, 2, 1)
+        else:
+            x = F.ConvBNAct.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
+                                  P["image_encoder.bn1.bias"], 2, 3, True, False)
+            x = F.MaxPool.apply(x, rt, 3, 2, 1)
         self._img_cut_out = self._img_cut_in = None
         for li in range(1, 5):
             if li == self._img_cut + 1 and self.cfg.use_lidar and rt.branch_streams and x.requires_grad:

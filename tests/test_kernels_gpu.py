@@ -330,6 +330,43 @@ def test_conv_bn_fwd_bwd(rts, dtype, case, relu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_fused_bn_relu_pool(rts, dtype):
+    """ImageEncoder stem as one node (conv -> BN -> ReLU -> max-pool, the last three fused; the backward gathers the pooled
+    gradient through the arg-max ids and rebuilds the ReLU mask from the conv output) against torch, and bit for bit against the
+    unfused kernels in the forward."""
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    B, H, Cin, Cout = 3, 38, 8, 64          # odd-sized maps: ragged pooling windows at the border
+    x = rnd(B, H, H, Cin, seed=1)
+    w = rnd(Cout, 7, 7, Cin, seed=2, scale=1 / math.sqrt(49 * Cin))
+    gamma, beta = 1 + 0.1 * rnd(Cout, seed=3), 0.1 * rnd(Cout, seed=4)
+    xq, wq = q(x, dtype), q(w, dtype).requires_grad_()
+    gq, bq = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    conv = ste(TF.conv2d(xq.permute(0, 3, 1, 2), wq.permute(0, 3, 1, 2), None, 2, 3), dtype)
+    act = ste(torch.relu(TF.batch_norm(conv, None, None, gq, bq, True, 0.0, 1e-5)), dtype)
+    ref = TF.max_pool2d(act, 3, 2, 1).permute(0, 2, 3, 1)
+    Wp, G, Bt = FakeParam(rt, w, "conv"), FakeParam(rt, gamma, "vec"), FakeParam(rt, beta, "vec")
+    anchor = torch.zeros(1, device=rt.device, requires_grad=True)
+    y = F.StemFn.apply(dev(x, rt), anchor, rt, Wp, G, Bt, 2, 3, 3, 2, 1)
+    check("y", y, ref, tol(dtype))
+    # forward values equal the unfused path exactly (same rounding point, same tie-break)
+    W2, G2, B2 = FakeParam(rt, w, "conv"), FakeParam(rt, gamma, "vec"), FakeParam(rt, beta, "vec")
+    y2 = F.MaxPool.apply(F.ConvBNAct.apply(dev(x, rt), anchor, rt, W2, G2, B2, 2, 3, True, False), rt, 3, 2, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    dy = rnd(*ref.shape, seed=5)
+    ref.backward(q(dy, dtype))
+    y.backward(dev(dy, rt))
+    y2.backward(dev(dy, rt))
+    check_grad("dw", Wp.g, wq.grad, tol(dtype, True) * 8, dtype, True)
+    check_grad("dgamma", G.g, gq.grad, tol(dtype, True) * 8, dtype, True)
+    check_grad("dbeta", Bt.g, bq.grad, tol(dtype, True) * 8, dtype, True)
+    # ... and the fused backward agrees with the unfused kernels (which round the un-pooled gradient to the storage type)
+    check("dw vs unfused", Wp.g, W2.g, tol(dtype, True) * 4)
+    check("dgamma vs unfused", G.g, G2.g, tol(dtype, True) * 4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("stride", [1, 2])
 def test_basic_block(rts, dtype, stride):
     from multimodal_sc_amd import functional as F
