@@ -134,15 +134,17 @@ int msc_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
                const float* gamma, const float* scale, const float* shift, void* dx, void* dres, float* dgamma,
                float* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate, int dtype, void* stream);
 /* ImageEncoder stem, BN + ReLU + max-pool (KxK / S, pad P) fused: the post-activation map is never materialised.
- * fwd: x = conv output [B,H,W,C], scale/shift from msc_bn_finalize -> pooled y [B,Ho,Wo,C] + arg-max tap ids idx (same values
- *      and tie-breaks as msc_bn_apply + msc_maxpool_fwd).
- * bwd: dpool = gradient w.r.t. y; the BatchNorm-backward passes gather it through idx and rebuild the ReLU mask from
- *      x*scale+shift > 0 -> dx [B,H,W,C] (gradient w.r.t. the conv output), dgamma, dbeta.  ws >= msc_bn_bwd_workspace_bytes(C). */
-int msc_bn_relu_pool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int B, int H, int W, int C,
-                         int K, int S, int P, int dtype, void* stream);
-int msc_bn_relu_pool_bwd(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* rstd,
-                         const float* gamma, const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta,
-                         float* ws, int B, int H, int W, int C, int K, int S, int P, int accumulate, int dtype, void* stream);
+ * fwd: x = conv output [B,H,W,C], scale/shift from msc_bn_finalize -> pooled y [B,Ho,Wo,C], arg-max tap ids idx (same values
+ *      and tie-breaks as msc_bn_apply + msc_maxpool_fwd) and xsel [B,Ho,Wo,C] = the conv output at each window's arg-max.
+ * bwd: dpool = gradient w.r.t. y.  Statistics pass on the pooled size (dpool, xsel; ReLU mask = xsel*scale+shift > 0), then one
+ *      pass that gathers dpool through idx -> dx [B,H,W,C] (gradient w.r.t. the conv output), dgamma, dbeta.
+ *      ws >= msc_bn_bwd_workspace_bytes(C). */
+int msc_bn_relu_pool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, void* xsel, int B, int H,
+                         int W, int C, int K, int S, int P, int dtype, void* stream);
+int msc_bn_relu_pool_bwd(const void* dpool, const uint8_t* idx, const void* xsel, const void* x, const float* mean,
+                         const float* rstd, const float* gamma, const float* scale, const float* shift, void* dx, float* dgamma,
+                         float* dbeta, float* ws, int B, int H, int W, int C, int K, int S, int P, int accumulate, int dtype,
+                         void* stream);
 int msc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int64_t rows, int D, float eps, int dtype, void* stream);
 int64_t msc_layernorm_bwd_workspace_bytes(int64_t rows, int D);

@@ -256,7 +256,7 @@ template <> __device__ __forceinline__ float round_store<bf16_t>(float v) { retu
 
 template <typename T>
 __global__ void bn_relu_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                        T* __restrict__ y, uint8_t* __restrict__ idx, int B, int C, PoolGeo g) {
+                                        T* __restrict__ y, uint8_t* __restrict__ idx, T* __restrict__ xsel, int B, int C, PoolGeo g) {
   constexpr int VEC = msc_traits<T>::VEC;
   const int cv = C / VEC;
   const long n = (long)B * g.Ho * g.Wo * cv;
@@ -267,12 +267,12 @@ __global__ void bn_relu_pool_fwd_kernel(const T* __restrict__ x, const float* __
     const int wo = (int)(t % (unsigned)g.Wo); t /= (unsigned)g.Wo;
     const int ho = (int)(t % (unsigned)g.Ho);
     const int b = (int)(t / (unsigned)g.Ho);
-    float sc[VEC], sh[VEC], best[VEC];
+    float sc[VEC], sh[VEC], best[VEC], bx[VEC];
     int bi[VEC];
     ldc<VEC>(scale + c0, sc);
     ldc<VEC>(shift + c0, sh);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; bx[j] = 0.f; }
     for (int kh = 0; kh < g.K; ++kh) {
       const int hi = ho * g.S - g.P + kh;
       if ((unsigned)hi >= (unsigned)g.H) continue;
@@ -285,15 +285,16 @@ __global__ void bn_relu_pool_fwd_kernel(const T* __restrict__ x, const float* __
         for (int j = 0; j < VEC; ++j) {
           float a = fmaf(v.v[j], sc[j], sh[j]);
           a = round_store<T>(a > 0.f ? a : 0.f);                 // the value bn_apply would have stored
-          if (a > best[j]) { best[j] = a; bi[j] = kh * g.K + kw; }
+          if (a > best[j]) { best[j] = a; bi[j] = kh * g.K + kw; bx[j] = v.v[j]; }
         }
       }
     }
-    vecf<T> o;
+    vecf<T> o, ox;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
+    for (int j = 0; j < VEC; ++j) { o.v[j] = best[j]; ox.v[j] = bx[j]; }
     const long oo = (((long)b * g.Ho + ho) * g.Wo + wo) * C + c0;
     o.store(y + oo);
+    ox.store(xsel + oo);       // the conv output at the arg-max: the backward's statistics pass runs on the pooled size
 #pragma unroll
     for (int j = 0; j < VEC; ++j) idx[oo + j] = (uint8_t)bi[j];
   }
@@ -323,59 +324,6 @@ __device__ __forceinline__ void pool_gather(const T* __restrict__ dpool, const u
       for (int j = 0; j < VEC; ++j)
         if (((taps >> (8 * j)) & 0xffu) == want) acc[j] += gr.v[j];
     }
-  }
-}
-
-// stage 1 (sums of dz and dz*xhat), incoming gradient gathered through the pool, ReLU mask rebuilt from x
-template <typename T>
-__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
-                                                                 const T* __restrict__ x, const float* __restrict__ mean,
-                                                                 const float* __restrict__ rstd, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, float* __restrict__ partial, long rows,
-                                                                 int C, int rows_per_block, PoolGeo g) {
-  constexpr int VEC = msc_traits<T>::VEC;
-  const int ncx = C / VEC, nty = 256 / ncx;
-  const int tx = threadIdx.x % ncx, ty = threadIdx.x / ncx;
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  const long r1 = min(rows, r0 + rows_per_block);
-  float s1[VEC], s2[VEC], mu[VEC], rs[VEC], sc[VEC], sh[VEC];
-  ldc<VEC>(mean + tx * VEC, mu);
-  ldc<VEC>(rstd + tx * VEC, rs);
-  ldc<VEC>(scale + tx * VEC, sc);
-  ldc<VEC>(shift + tx * VEC, sh);
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  if (ty < nty) {
-    for (long r = r0 + ty; r < r1; r += nty) {
-      const unsigned ru = (unsigned)r;
-      const int w = (int)(ru % (unsigned)g.W);
-      const unsigned t = ru / (unsigned)g.W;
-      const int h = (int)(t % (unsigned)g.H), b = (int)(t / (unsigned)g.H);
-      float dz[VEC];
-      pool_gather<T>(dpool, idx, b, h, w, C, tx * VEC, g, dz);
-      vecf<T> vx;
-      vx.load(x + r * C + tx * VEC);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float d = fmaf(vx.v[j], sc[j], sh[j]) > 0.f ? dz[j] : 0.f;
-        s1[j] += d;
-        s2[j] += d * (vx.v[j] - mu[j]) * rs[j];
-      }
-    }
-  }
-  __shared__ float red[2][2048];
-  float* r1p = &red[0][0];
-  float* r2p = &red[1][0];
-  if (ty < nty) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) { r1p[ty * C + tx * VEC + j] = s1[j]; r2p[ty * C + tx * VEC + j] = s2[j]; }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f, bb = 0.f;
-    for (int t = 0; t < nty; ++t) { a += r1p[t * C + c]; bb += r2p[t * C + c]; }
-    partial[(long)blockIdx.x * 2 * C + c] = a;
-    partial[(long)blockIdx.x * 2 * C + C + c] = bb;
   }
 }
 
@@ -721,9 +669,9 @@ extern "C" int msc_bn_bwd(const void* dy, const void* x, const void* y, const fl
 }
 
 // ---- stem: BN + ReLU + max-pool fused (see the kernels above).  x: conv output [B,H,W,C]; y/idx: [B,Ho,Wo,C]
-extern "C" int msc_bn_relu_pool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int B, int H, int W,
-                                    int C, int K, int S, int P, int dtype, void* stream) {
-  MSC_CHECK_ARG(x && scale && shift && y && idx && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && K * K <= 255 && S > 0 && P >= 0);
+extern "C" int msc_bn_relu_pool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, void* xsel, int B, int H,
+                                    int W, int C, int K, int S, int P, int dtype, void* stream) {
+  MSC_CHECK_ARG(x && scale && shift && y && idx && xsel && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && K * K <= 255 && S > 0 && P >= 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   PoolGeo g = {H, W, (H + 2 * P - K) / S + 1, (W + 2 * P - K) / S + 1, K, S, P};
   MSC_CHECK_ARG(g.Ho > 0 && g.Wo > 0);
@@ -731,33 +679,36 @@ extern "C" int msc_bn_relu_pool_fwd(const void* x, const float* scale, const flo
   if (dtype == MSC_F32) {
     MSC_CHECK_ARG(C % 4 == 0 && (long)B * g.Ho * g.Wo * C / 4 < 0x7fffffffL);
     hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, (const float*)x, scale,
-                       shift, (float*)y, idx, B, C, g);
+                       shift, (float*)y, idx, (float*)xsel, B, C, g);
   } else {
     MSC_CHECK_ARG(C % 8 == 0 && (long)B * g.Ho * g.Wo * C / 8 < 0x7fffffffL);
     hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16_t>, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 8)), dim3(256), 0, st, (const bf16_t*)x,
-                       scale, shift, (bf16_t*)y, idx, B, C, g);
+                       scale, shift, (bf16_t*)y, idx, (bf16_t*)xsel, B, C, g);
   }
   return msc_launch_status();
 }
 
 template <typename T>
-static int bn_pool_bwd_t(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* rstd, const float* gamma,
-                         const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta, float* ws, int B, int C,
-                         PoolGeo g, int accumulate, hipStream_t st) {
+static int bn_pool_bwd_t(const void* dpool, const uint8_t* idx, const void* xsel, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta, float* ws, int B,
+                         int C, PoolGeo g, int accumulate, hipStream_t st) {
   constexpr int VEC = msc_traits<T>::VEC;
   if (C % VEC || C / VEC > 256) return MSC_ERR_BAD_ARG;
   const int ncx = C / VEC, nty = 256 / ncx;
   if (nty < 1 || (long)nty * C > 2048) return MSC_ERR_BAD_ARG;
   const long rows = (long)B * g.H * g.W;
   if (rows * (C / VEC) >= 0x7fffffffL) return MSC_ERR_UNSUPPORTED;
-  int nblk = cdiv(rows, 128);
+  // statistics pass on the POOLED size: sum over windows of dpool*[relu'] and dpool*[relu']*xhat at the window's arg-max (xsel) equals
+  // the sum over pixels of the gathered gradient — the generic BatchNorm-backward reduction with dy = dpool, x = xsel
+  const long prow = (long)B * g.Ho * g.Wo;
+  int nblk = cdiv(prow, 128);
   if (nblk > BN_MAX_BLOCKS) nblk = BN_MAX_BLOCKS;
-  const int rpb = cdiv(rows, nblk);
-  nblk = cdiv(rows, rpb);
+  const int rpb = cdiv(prow, nblk);
+  nblk = cdiv(prow, rpb);
   float* partial = ws;
   float* sums = ws + (long)BN_MAX_BLOCKS * 2 * C;
-  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dpool, idx, (const T*)x, mean, rstd, scale, shift,
-                     partial, rows, C, rpb, g);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dpool, (const T*)xsel, (const T*)nullptr, mean, rstd, scale,
+                     shift, partial, prow, C, 1, rpb);
   launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
   const long nvec = rows * C / VEC;
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dpool, idx, (const T*)x, mean, rstd, gamma,
@@ -765,17 +716,20 @@ static int bn_pool_bwd_t(const void* dpool, const uint8_t* idx, const void* x, c
   return msc_launch_status();
 }
 
-// dpool: gradient w.r.t. the pooled map [B,Ho,Wo,C]; dx: gradient w.r.t. the conv output x [B,H,W,C]; ws as msc_bn_bwd
-extern "C" int msc_bn_relu_pool_bwd(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* rstd,
-                                    const float* gamma, const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta,
-                                    float* ws, int B, int H, int W, int C, int K, int S, int P, int accumulate, int dtype, void* stream) {
-  MSC_CHECK_ARG(dpool && idx && x && mean && rstd && gamma && scale && shift && dx && dgamma && dbeta && ws);
+// dpool: gradient w.r.t. the pooled map [B,Ho,Wo,C]; xsel: from the forward; dx: gradient w.r.t. the conv output x [B,H,W,C]; ws as msc_bn_bwd
+extern "C" int msc_bn_relu_pool_bwd(const void* dpool, const uint8_t* idx, const void* xsel, const void* x, const float* mean,
+                                    const float* rstd, const float* gamma, const float* scale, const float* shift, void* dx, float* dgamma,
+                                    float* dbeta, float* ws, int B, int H, int W, int C, int K, int S, int P, int accumulate, int dtype,
+                                    void* stream) {
+  MSC_CHECK_ARG(dpool && idx && xsel && x && mean && rstd && gamma && scale && shift && dx && dgamma && dbeta && ws);
   MSC_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && S > 0 && P >= 0);
   PoolGeo g = {H, W, (H + 2 * P - K) / S + 1, (W + 2 * P - K) / S + 1, K, S, P};
   MSC_CHECK_ARG(g.Ho > 0 && g.Wo > 0);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MSC_F32) return bn_pool_bwd_t<float>(dpool, idx, x, mean, rstd, gamma, scale, shift, dx, dgamma, dbeta, ws, B, C, g, accumulate, st);
-  if (dtype == MSC_BF16) return bn_pool_bwd_t<bf16_t>(dpool, idx, x, mean, rstd, gamma, scale, shift, dx, dgamma, dbeta, ws, B, C, g, accumulate, st);
+  if (dtype == MSC_F32)
+    return bn_pool_bwd_t<float>(dpool, idx, xsel, x, mean, rstd, gamma, scale, shift, dx, dgamma, dbeta, ws, B, C, g, accumulate, st);
+  if (dtype == MSC_BF16)
+    return bn_pool_bwd_t<bf16_t>(dpool, idx, xsel, x, mean, rstd, gamma, scale, shift, dx, dgamma, dbeta, ws, B, C, g, accumulate, st);
   return MSC_ERR_BAD_ARG;
 }
 

@@ -128,25 +128,26 @@ class StemFn(torch.autograd.Function):
         Hp, Wp = (Ho + 2 * pP - pK) // pS + 1, (Wo + 2 * pP - pK) // pS + 1
         y = rt.empty(B, Hp, Wp, Cout)
         idx = torch.empty(B, Hp, Wp, Cout, dtype=torch.uint8, device=x.device)
-        rt.call("msc_bn_relu_pool_fwd", y_raw, stats[2], stats[3], y, idx, B, Ho, Wo, Cout, pK, pS, pP, rt.dt)
+        xsel = rt.empty(B, Hp, Wp, Cout)      # conv output at each window's arg-max: the backward's statistics pass reads this, not y_raw
+        rt.call("msc_bn_relu_pool_fwd", y_raw, stats[2], stats[3], y, idx, xsel, B, Ho, Wo, Cout, pK, pS, pP, rt.dt)
         if rt.taps is not None:   # parity tests compare ReLU masks: materialise the activation the fused pass never stores
             act = rt.empty(B, Ho, Wo, Cout)
             rt.call("msc_bn_apply", y_raw, stats[2], stats[3], None, act, M, Cout, 1, rt.dt)
             rt.taps[conv.name] = act
-        ctx.save_for_backward(x, y_raw, stats, idx)
+        ctx.save_for_backward(x, y_raw, stats, idx, xsel)
         ctx.cfg = (rt, conv, gamma, beta, stride, pad, pK, pS, pP)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y_raw, stats, idx = ctx.saved_tensors
+        x, y_raw, stats, idx, xsel = ctx.saved_tensors
         rt, conv, gamma, beta, stride, pad, pK, pS, pP = ctx.cfg
         B, H, W, Cin = x.shape
         Cout, KH, KW, _ = conv.shape
         _, Ho, Wo, _ = y_raw.shape
         d_raw = torch.empty_like(y_raw)
         ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
-        rt.call("msc_bn_relu_pool_bwd", dy.contiguous(), idx, y_raw, stats[0], stats[1], gamma.p, stats[2], stats[3], d_raw, gamma.g, beta.g,
+        rt.call("msc_bn_relu_pool_bwd", dy.contiguous(), idx, xsel, y_raw, stats[0], stats[1], gamma.p, stats[2], stats[3], d_raw, gamma.g, beta.g,
                 ws, B, Ho, Wo, Cout, pK, pS, pP, rt.accumulate, rt.dt)
         wsb = L.query("msc_wgrad_workspace_bytes", Cout, KH * KW * Cin, B * Ho * Wo)
         if _STEM_WGRAD_MAIN:     # last node of the backward: nothing left on the launching stream to hide behind (see conv_bn_bwd)
