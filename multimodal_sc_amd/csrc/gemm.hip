@@ -44,6 +44,7 @@ struct GemmParams {
   // geometry of the gathered NHWC tensor (conv modes)
   int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
   int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
+  int cls_interleave;       // set by the launcher when cMc is a multiple of the tile height it picked
   unsigned long long* stamps;   // GEMM_STAMP diagnostic build only (else null and unused)
   int bm_cap;                   // host only: largest tile height the launch may use (0 = no cap)
   float* rowsum;                // weight-gradient launches (both operands mn-major): fp32 [nsplit][M] sums over the reduction of the
@@ -420,6 +421,16 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm
       }
     }
     g.tile_m = bid / ntn; g.tile_n = bid % ntn;
+    if constexpr (AMODE == OPM_CONV_DGRAD) {
+      // strided dgrad, rows in parity-class-major order: the S*S classes of one pixel region gather the SAME rows of dy, so
+      // their row tiles are made neighbours in launch order (same XCD, same time: dy comes from HBM once instead of S*S times)
+      if (p.cls_interleave) {
+        const int ncls = p.cS * p.cS, tpc = p.cMc / BM;
+        const int region = bid / (ncls * ntn), rem = bid - region * (ncls * ntn);
+        g.tile_m = (rem / ntn) * tpc + region;
+        g.tile_n = rem % ntn;
+      }
+    }
     g.m0 = g.tile_m * BM; g.n0 = g.tile_n * BN;
     g.zo = zz / p.batch_inner; g.zi = zz % p.batch_inner;
   };
@@ -1052,14 +1063,17 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   const bool big = p.nsplit == 1 && !p.xcd_split && !p.stats && !p.colsum;
   const mscplan::Tile t = tile_for(p.M, p.N, zs, AMODE, BMODE, DT, p.K, big, p.bm_cap ? p.bm_cap : 256);
   const int bm = t.bm, bn = t.bn;
+  GemmParams q = p;
+  static const int cls_il = getenv("MSC_DGRAD_CLS_INTERLEAVE") ? atoi(getenv("MSC_DGRAD_CLS_INTERLEAVE")) : 1;   // A/B knob
+  q.cls_interleave = (AMODE == OPM_CONV_DGRAD && p.cls && cls_il && p.nsplit == 1 && p.cMc % bm == 0) ? 1 : 0;
   if (zs > 65535) return MSC_ERR_UNSUPPORTED;
   if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
     if (bm == 256) {     // persistent: one workgroup per CU walks the tiles
       const int ntiles = cdiv(p.M, 256) * cdiv(p.N, bn);
       const int ncu = num_cus();
       dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu), 1, 1);
-      if (bn == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 256, EPX, GEMM_P256_KB, GEMM_P256_STAGES, true, 512>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, GEMM_P128_KB, GEMM_P128_STAGES, true, 512>), grid, dim3(512), 0, st, p);
+      if (bn == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 256, EPX, GEMM_P256_KB, GEMM_P256_STAGES, true, 512>), grid, dim3(512), 0, st, q);
+      else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, GEMM_P128_KB, GEMM_P128_STAGES, true, 512>), grid, dim3(512), 0, st, q);
       return msc_launch_status();
     }
   }
@@ -1070,10 +1084,10 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   // everything else on 128-byte steps x 2 stages, the 128x128 tile with 8 waves
   constexpr bool WG = BMODE == OPM_CONV_WGRAD;
   constexpr int KBn = WG ? 64 : GEMM_NP_KB, S = WG ? GEMM_WG_STAGES : GEMM_NP_STAGES, W128 = WG ? 256 : 64 * GEMM_NP_W128;
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX, KBn, S, false, W128>), grid, dim3(W128), 0, st, p);
-  else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, p);
-  else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64, EPX, KBn, S + 1, false, 256>), grid, dim3(256), 0, st, p);
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX, KBn, S, false, W128>), grid, dim3(W128), 0, st, q);
+  else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, q);
+  else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 64, EPX, KBn, S + 1, false, 256>), grid, dim3(256), 0, st, q);
   return msc_launch_status();
 }
 
