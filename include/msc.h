@@ -214,13 +214,16 @@ int msc_channel_bwd(const void* dy, const void* x, const float* scale, void* dx,
 int msc_philox_normal(float* out, int64_t nquads, uint64_t seed, uint32_t stream_id, uint64_t draw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * LiDAR / BEV encoder front end: point MLP (4->64, ReLU) + scatter-max into [B][G][G][64]. */
-int msc_pillar_fwd(const float* points, const float* w, const float* bias, float* grid_f32, void* grid_out, int B,
-                   int Np, int G, int C, float range_lo, float cell, int dtype, void* stream);
+ * LiDAR / BEV encoder front end: point MLP (4->64, ReLU) + max over the points of each BEV cell -> [B][G][G][64].
+ * Gather formulation: the forward bins each frame's points by cell (sorted_pts fp32 [B*Np][4], cell_start int32
+ * [B][G*G+1] = msc_pillar_index_bytes, rank int32 [B*Np] scratch) and writes the grid in the storage type; the backward walks
+ * the same bins (points outside the grid are dropped by the binning).  G*G <= 32768. */
+int64_t msc_pillar_index_bytes(int B, int G);
+int msc_pillar_fwd(const float* points, const float* w, const float* bias, float* sorted_pts, int32_t* cell_start, int32_t* rank,
+                   void* grid_out, int B, int Np, int G, int C, float range_lo, float cell, int dtype, void* stream);
 int64_t msc_pillar_bwd_workspace_bytes(void);
-int msc_pillar_bwd(const float* points, const float* w, const float* bias, const float* grid_f32,
-                   const void* dgrid, float* dw, float* db, float* ws, int B, int Np, int G, int C, float range_lo,
-                   float cell, int accumulate, int dtype, void* stream);
+int msc_pillar_bwd(const float* sorted_pts, const int32_t* cell_start, const float* w, const float* bias, const void* dgrid,
+                   float* dw, float* db, float* ws, int B, int G, int C, int accumulate, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Policy / value head, losses, attention softmax. */

@@ -151,7 +151,18 @@ static inline WgradSplit wgrad_split(long rows_out, long cols_out, long reduce_l
   w.tps = (int)cdivl(nk, planned);
   w.ns = (int)cdivl(nk, w.tps);
   static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;
-  w.xcd_split = (xs && w.ns >= 8 && w.ns % 8 == 0) ? 1 : 0;
+  // the slice count that really runs is cdiv(nk, tps), often planned - 1: lengthen the slices a little (at most 25 %) until
+  // it is a multiple of 8 again, or the XCD pinning below silently never applies (layer 1 at 64 frames: 104 planned, 103 ran)
+  if (xs && planned >= 8 && w.ns % 8 != 0) {
+    for (long t = w.tps + 1; t <= w.tps + w.tps / 4 + 1; ++t) {
+      const long n = cdivl(nk, t);
+      if (n >= 8 && n % 8 == 0) { w.tps = (int)t; w.ns = (int)n; break; }
+    }
+  }
+  // measured (tools/gemm_bench.py, MSC_WGRAD_XCD_SPLIT=0/1): -8..-17 % where a slice has few tiles or many K steps (layer 1/2, BEV,
+  // qkv), +15 % on layer 3 (36 tiles x 25 steps per slice) — short slices of many tiles stay on the plain mapping
+  const long tiles = cdivl(rows_out, 128) * cdivl(cols_out, cols_out <= 64 ? 64 : 128);
+  w.xcd_split = (xs && w.ns >= 8 && w.ns % 8 == 0 && !(tiles > 32 && w.tps < 32)) ? 1 : 0;
   w.ws_bytes = (int64_t)planned * rows_out * (cols_out + 1) * 4;
   return w;
 }

@@ -556,19 +556,21 @@ class PillarFn(torch.autograd.Function):
         B, Np, _ = points.shape
         C = w.shape[0]
         cell = 2.0 * rng / G
-        grid32 = rt.f32(B, G, G, C)
-        out = grid32 if rt.dt == L.MSC_F32 else rt.empty(B, G, G, C)
-        rt.call("msc_pillar_fwd", points, w.p, b.p, grid32, out, B, Np, G, C, -rng, cell, rt.dt)
-        ctx.save_for_backward(points, grid32)
-        ctx.cfg = (rt, w, b, G, rng, cell)
+        # bins of the frame's points by BEV cell (written by the forward, walked again by the backward)
+        sorted_pts = rt.f32(B * Np, 4)
+        cell_start = torch.empty(L.query("msc_pillar_index_bytes", B, G) // 4, dtype=torch.int32, device=points.device)
+        rank = torch.empty(B * Np, dtype=torch.int32, device=points.device)
+        out = rt.empty(B, G, G, C)
+        rt.call("msc_pillar_fwd", points, w.p, b.p, sorted_pts, cell_start, rank, out, B, Np, G, C, -rng, cell, rt.dt)
+        ctx.save_for_backward(sorted_pts, cell_start)
+        ctx.cfg = (rt, w, b, G, B)
         return out
 
     @staticmethod
     def backward(ctx, dgrid):
-        points, grid32 = ctx.saved_tensors
-        rt, w, b, G, rng, cell = ctx.cfg
-        B, Np, _ = points.shape
+        sorted_pts, cell_start = ctx.saved_tensors
+        rt, w, b, G, B = ctx.cfg
         ws = rt.workspace("pillar", L.query("msc_pillar_bwd_workspace_bytes"), per_stream=False)
-        rt.call_side("msc_pillar_bwd", points, w.p, b.p, grid32, dgrid.contiguous(), w.g, b.g, ws, B, Np, G, w.shape[0], -rng, cell,
-                rt.accumulate, rt.dt)
+        rt.call_side("msc_pillar_bwd", sorted_pts, cell_start, w.p, b.p, dgrid.contiguous(), w.g, b.g, ws, B, G, w.shape[0],
+                     rt.accumulate, rt.dt)
         return None, None, None, None, None, None, None

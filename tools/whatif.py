@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""What-if timing of the training step: SKIP the C-ABI calls whose name matches a regex (results are WRONG by construction —
+this only answers "how much of the step does that work cost as scheduled", i.e. what a perfect speed-up of it could buy).
+Usage: whatif.py [regex ...]     e.g.  whatif.py 'wgrad'  'msc_bn_bwd|msc_bn_apply'  'msc_pillar'
+Prints ms/step (median of 3 x 30 steps) for the baseline and for each regex, all in one process on one box."""
+import os, re, sys, statistics, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_sc_amd.model import MultimodalSC, named_config
+from multimodal_sc_amd.synthetic import synthetic_batch
+from multimodal_sc_amd.trainer import Trainer
+from multimodal_sc_amd import lib as L
+
+cfg = named_config(os.environ.get("CFG", "C3"))
+B = int(os.environ.get("B", "64"))
+m = MultimodalSC(cfg, "bf16", "cuda:0")
+tr = Trainer(m, lr=0.0)      # parameters never move: skipped kernels cannot poison later steps (NaN data also changes power/clocks)
+cb = synthetic_batch(cfg, B, seed=1)
+b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cb.items() if k != "ppo"}
+b["ppo"] = {k: v.cuda() for k, v in cb["ppo"].items()}
+b["noise"] = b["fading"] = None
+orig = L.call
+skip = [None]
+
+
+def call(name, *a):
+    if skip[0] is not None and skip[0].search(name):
+        return 0
+    return orig(name, *a)
+
+
+L.call = call
+
+
+def timed(n=30):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.step(b)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for _ in range(5):
+    tr.step(b)
+def measure(rx):
+    skip[0] = re.compile(rx) if rx else None
+    tr.step(b)
+    return statistics.median([timed() for _ in range(3)])
+
+
+for rx in sys.argv[1:]:
+    b0 = measure(None)      # a fresh baseline before every variant: the box drifts by several 0.1 ms over a minute
+    v = measure(rx)
+    print(f"skip {rx:44s} {v:7.3f} ms/step   baseline {b0:7.3f}   delta {v - b0:+.3f}")
