@@ -621,6 +621,51 @@ def test_pillar(rts, dtype):
         assert rel < 2e-2, f"{name}: relative Frobenius error {rel:.3e}"
 
 
+@pytest.mark.parametrize("case", ["all_outside", "one_cell", "duplicates", "ragged"])
+def test_pillar_edge_cases(rts, case):
+    """collisions and empties of the BEV binning against the oracle (f32 mode, tight): every point outside the grid (empty grid, zero
+    gradients), every point of a frame in ONE cell (a 3000-point bin), exact duplicates (tied maxima share the gradient evenly, as
+    scatter_reduce(amax) does), and frames with very different numbers of valid points"""
+    from multimodal_sc_amd import functional as F
+    from oracle.model import BEVEncoder, MSCConfig
+    rt = rts["f32"]
+    cfg = MSCConfig(bev_grid=32, bev_range=12.8)
+    B, Np = 3, 3000
+    g = torch.Generator().manual_seed(11)
+    pts = torch.cat([(torch.rand(B, Np, 2, generator=g) * 2 - 1) * 12.0, torch.rand(B, Np, 2, generator=g)], -1)
+    if case == "all_outside":
+        pts[..., 0] += 100.0
+    elif case == "one_cell":
+        pts[0, :, 0] = 0.1 + 0.5 * torch.rand(Np, generator=g)          # frame 0: one 0.8 m cell holds all 3000 points
+        pts[0, :, 1] = 0.1 + 0.5 * torch.rand(Np, generator=g)
+    elif case == "duplicates":
+        pts[:, 1::2] = pts[:, 0::2]                                       # every point twice: every maximum is a two-way tie
+    elif case == "ragged":
+        pts[1, 100:, 0] = 1e3                                             # frame 1 keeps 100 points, frame 2 none
+        pts[2, :, 1] = 1e6
+    torch.manual_seed(99)
+    enc = BEVEncoder(cfg)
+    ref_in = pts
+    ref = enc.pillar_grid(ref_in)
+    dy = rnd(*ref.shape, seed=3)
+    ref.backward(dy)
+    W, Bp = FakeParam(rt, enc.point_mlp.weight.detach(), "vec"), FakeParam(rt, enc.point_mlp.bias.detach(), "vec")
+    anchor = torch.zeros(1, device=rt.device, requires_grad=True)
+    out = F.PillarFn.apply(ref_in.to(rt.device), anchor, rt, W, Bp, cfg.bev_grid, cfg.bev_range)
+    check("grid", out, ref, 1e-5)
+    out.backward(dy.to(rt.device))
+    torch.cuda.synchronize()
+    for name, got, want in (("dw", W.g, enc.point_mlp.weight.grad), ("db", Bp.g, enc.point_mlp.bias.grad)):
+        g64, r64 = got.double().cpu(), want.double()
+        assert torch.isfinite(g64).all(), name
+        den = r64.norm().item()
+        if den == 0.0:
+            assert g64.abs().max().item() == 0.0, name
+        else:
+            rel = ((g64 - r64).norm() / den).item()
+            assert rel < 2e-3, f"{case} {name}: relative Frobenius error {rel:.3e}"
+
+
 # ------------------------------------------------------------------------------------------------ heads / losses
 def test_argmax_ties_bit_exact(rts):
     for dtype in DTYPES:
