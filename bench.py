@@ -30,7 +30,10 @@ PMC_HBM_SUMMARY = "profiles/r2_pmc_hbm_bench_c3.csv"
 
 def gemm_source_sha():
     import hashlib
-    return hashlib.sha256(open(os.path.join(ROOT, "multimodal_sc_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm_plan.h"):        # the kernel and its launch planning (tile choice, split counts)
+        h.update(open(os.path.join(ROOT, "multimodal_sc_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_hbm_bytes_per_gemm_launch():
@@ -46,7 +49,7 @@ def pmc_hbm_bytes_per_gemm_launch():
     if not (os.path.exists(path) and os.path.exists(meta)):
         return None, "no PMC summary for this build"
     if json.load(open(meta)).get("gemm_hip_sha256_16") != gemm_source_sha():
-        return None, f"{PMC_HBM_SUMMARY} is stale (csrc/gemm.hip changed since the PMC pass)"
+        return None, f"{PMC_HBM_SUMMARY} is stale (csrc/gemm.hip or gemm_plan.h changed since the PMC pass)"
     b = n = 0.0
     for r in csv.DictReader(open(path)):
         if "gemm_kernel<unsigned short" in r["kernel"]:

@@ -114,13 +114,14 @@ static inline ConvSplit conv_split(long M, long N, long k_len, int dtype_is_f32)
 // split-K of the weight-gradient GEMMs (output rows_out x cols_out, reduction over reduce_len pixels / tokens)
 static inline int plan_split(long rows_out, long cols_out, long reduce_len) {
   const long tiles = cdivl(rows_out, 128) * cdivl(cols_out, cols_out <= 64 ? 64 : 128);
-  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~512 workgroups measured best
-  // (fewer: underfilled when the main stream idles; more: fp32 slab traffic = nsplit x output)
+  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~768 workgroups measured best
+  // (fewer: underfilled when the main stream idles; more: fp32 slab traffic = nsplit x output).  Same-box sweep of the step
+  // at the end of round 2 (XCD pinning really applied): 384: +0.06 ms, 512: 0, 768: -0.07, 1024 / 1536 / 2048: -0.05.
   static long target = 0;
   if (!target) {
-    const char* e = getenv("MSC_WGRAD_BLOCKS");   // tuning knob (A/B runs); default 512 (measured best of 128..1536)
-    target = e ? atol(e) : 512;
-    if (target < 1) target = 512;
+    const char* e = getenv("MSC_WGRAD_BLOCKS");   // tuning knob (A/B runs)
+    target = e ? atol(e) : 768;
+    if (target < 1) target = 768;
   }
   long want = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
   long cap = reduce_len / 1024;

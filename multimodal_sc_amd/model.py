@@ -141,7 +141,11 @@ class MultimodalSC:
         self.rt = Runtime(dtype, device)
         self.params = ParamStore(self.rt, param_specs(cfg))
         self.anchor = torch.zeros(1, device=self.rt.device, requires_grad=True)
-        self._img_cut = int(os.environ.get("MSC_IMG_CUT", "3"))   # trunk layers below the backward boundary (0 = none)
+        # trunk layers below the backward boundary of backward_lower (0 or 4 = no boundary).  Single GPU: none — since the pillar front
+        # end became cheap the BEV-branch backward is enqueued quickly and the boundary only costs (same-box: 8.25 -> 8.12 ms).
+        # Data parallel: 3, which is what gives the gradient exchange its mid piece (Trainer sets it when MSC_IMG_CUT is not given).
+        self._img_cut_auto = "MSC_IMG_CUT" not in os.environ
+        self._img_cut = int(os.environ.get("MSC_IMG_CUT", "4"))
         self._img_cut_out = self._img_cut_in = None
         self._bev_slot = None
         # in-kernel channel noise (throughput mode): Philox key = (channel_seed, channel_rank), counter word = draw_dev, a

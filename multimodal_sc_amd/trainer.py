@@ -116,6 +116,8 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if self.world > 1:
             model.channel_rank = dist.get_rank()      # every rank draws its own channel noise (Philox key word)
+            if getattr(model, "_img_cut_auto", False):
+                model._img_cut = 3                    # boundary inside the camera trunk: the exchange's mid piece starts there
         self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
         self.split = model.params.refs["fusion.pos_embed"].off
         self.use_graph = os.environ.get("MSC_HIP_GRAPH", "0") == "1"
