@@ -145,6 +145,8 @@ int msc_bn_relu_pool_bwd(const void* dpool, const uint8_t* idx, const void* xsel
                          const float* rstd, const float* gamma, const float* scale, const float* shift, void* dx, float* dgamma,
                          float* dbeta, float* ws, int B, int H, int W, int C, int K, int S, int P, int accumulate, int dtype,
                          void* stream);
+/* out[i] = (accumulate ? out[i] : 0) + (a[i] + b[i]), fp32: sums the LayerNorm parameter gradients of the two half-batch chains */
+int msc_add2_f32(const float* a, const float* b, float* out, int64_t n, int accumulate, void* stream);
 int msc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int64_t rows, int D, float eps, int dtype, void* stream);
 int64_t msc_layernorm_bwd_workspace_bytes(int64_t rows, int D);

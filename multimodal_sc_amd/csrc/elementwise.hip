@@ -419,6 +419,18 @@ extern "C" int msc_cast(const float* src, void* dst, int64_t n, int dtype, void*
   return msc_launch_status();
 }
 
+__global__ void add2_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = (accumulate ? out[i] : 0.f) + (a[i] + b[i]);
+}
+// out = (accumulate ? out : 0) + (a + b): the two half-batch chains of a fusion layer each finalize their LayerNorm parameter
+// gradients into scratch; this adds them into G in a fixed order
+extern "C" int msc_add2_f32(const float* a, const float* b, float* out, int64_t n, int accumulate, void* stream) {
+  MSC_CHECK_ARG(a && b && out && n > 0);
+  hipLaunchKernelGGL(add2_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n, accumulate);
+  return msc_launch_status();
+}
+
 extern "C" int msc_permute3_cast(const float* src, void* dst, int d0, int d1, int d2, int dtype, void* stream) {
   MSC_CHECK_ARG(src && dst && d0 > 0 && d1 > 0 && d2 > 0 && d1 <= 65535);
   dim3 grid((unsigned)cdiv(d2, 32), (unsigned)cdiv(d0, 32), (unsigned)d1);

@@ -448,6 +448,111 @@ def attention_bwd(rt: Runtime, do, qkv, o, P, B, T, h, hd):
     return dqkv
 
 
+_FUSION_CHAINS = os.environ.get("MSC_FUSION_CHAINS", "2") != "1"     # A/B knob: 1 = the whole batch as one chain of launches
+
+
+def _two_chains_ok(rt: Runtime, B, T, hd):
+    """The fusion layers run the two halves of the batch as two chains of launches on two streams (the BEV-branch stream is idle
+    during the fusion).  Every kernel of a layer is per-sample, so nothing changes numerically; the workgroups of ONE launch run
+    their load / MFMA / store phases in lock-step, two concurrent half-size launches interleave them (tools/two_chain_probe.py:
+    the four forward linears of a layer 255 -> 207 us).  Weight gradients still run ONCE over the whole batch (the halves are
+    row ranges of the same buffers)."""
+    return _FUSION_CHAINS and _FUSED_BIAS and B >= 2 and rt.branch_streams and rt.side_active() and fused_attention_ok(rt, T, hd)
+
+
+def _fusion_fwd_two_chains(ctx, x, rt, p, h):
+    B, T, D = x.shape
+    hd, M, Fh = D // h, B * T, p["fc1w"].shape[0]
+    main = rt.stream
+    s2, ev_ab, ev_ba, _ = rt.chain_b()
+    x2d = x.reshape(M, D)
+    h1, qkv, o, x1, h2 = rt.empty(M, D), rt.empty(M, 3 * D), rt.empty(M, D), rt.empty(M, D), rt.empty(M, D)
+    upre, u, x2 = rt.empty(M, Fh), rt.empty(M, Fh), rt.empty(M, D)
+    st = rt.f32(4, M)                                              # mu1, rs1, mu2, rs2
+    lse = rt.f32(B * h, L.query("msc_attention_tpad", T))
+    scale = 1.0 / math.sqrt(hd)
+    if p.get("first", True):                                            # the tokens were assembled on the main stream
+        L.call("msc_stream_wait_stream", s2, main, ev_ab)
+    Bh = B // 2
+    chains = ((main, 0, Bh), (s2, Bh, B))
+    # the two chains' launches are enqueued alternately, kernel by kernel
+    def each(fn):
+        for strm, b0, b1 in chains:
+            fn(strm, slice(b0 * T, b1 * T), slice(b0 * h, b1 * h), b1 - b0)
+    each(lambda c, r, bh, nb: L.call("msc_layernorm_fwd", x2d[r], p["ln1g"].p, p["ln1b"].p, h1[r], st[0][r], st[1][r], nb * T, D, LN_EPS, rt.dt, c))
+    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", h1[r], p["qkvw"].c, p["qkvb"].p, None, qkv[r], None, nb * T, 3 * D, D, L.ACT_NONE, rt.dt, c))
+    each(lambda c, r, bh, nb: L.call("msc_attention_fwd", qkv[r], o[r], lse[bh], nb, T, h, hd, scale, rt.dt, c))
+    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", o[r], p["projw"].c, p["projb"].p, x2d[r], x1[r], None, nb * T, D, D, L.ACT_NONE, rt.dt, c))
+    each(lambda c, r, bh, nb: L.call("msc_layernorm_fwd", x1[r], p["ln2g"].p, p["ln2b"].p, h2[r], st[2][r], st[3][r], nb * T, D, LN_EPS, rt.dt, c))
+    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", h2[r], p["fc1w"].c, p["fc1b"].p, None, u[r], upre[r], nb * T, Fh, D, L.ACT_GELU, rt.dt, c))
+    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", u[r], p["fc2w"].c, p["fc2b"].p, x1[r], x2[r], None, nb * T, D, Fh, L.ACT_NONE, rt.dt, c))
+    if p.get("last", True):                                             # the final LayerNorm reads the whole batch on the main stream
+        L.call("msc_stream_wait_stream", main, s2, ev_ba)
+    ctx.save_for_backward(x2d, st, h1, qkv, lse, o, x1, h2, upre, u)
+    ctx.cfg = (rt, p, h, (B, T, D))
+    ctx.two = True
+    return x2.view(B, T, D)
+
+
+def _fusion_bwd_two_chains(ctx, dy):
+    rt, p, h, (B, T, D) = ctx.cfg
+    hd, M, Fh = D // h, B * T, p["fc1w"].shape[0]
+    x2d, st, h1, qkv, lse, o, x1, h2, upre, u = ctx.saved_tensors
+    main = rt.stream
+    s2, ev_ab, ev_ba, ev_bs = rt.chain_b()
+    dx2 = dy.reshape(M, D).contiguous()
+    dpre, dh2, dx1, do = rt.empty(M, Fh), rt.empty(M, D), rt.empty(M, D), rt.empty(M, D)
+    dqkv, dh1, dx = rt.empty(M, 3 * D), rt.empty(M, D), rt.empty(M, D)
+    delta = rt.f32(*lse.shape)
+    lnt = rt.f32(2, 2, 2 * D)                                      # [chain][ln1 | ln2][dgamma | dbeta]
+    scale = 1.0 / math.sqrt(hd)
+    if p.get("last", True):                                             # dy comes from the final LayerNorm's backward on the main stream
+        L.call("msc_stream_wait_stream", s2, main, ev_ab)
+    Bh = B // 2
+    chains = ((main, 0, Bh, 0), (s2, Bh, B, 1))
+    lnws = [rt.workspace(f"ln_bwd_chain{ci}", L.query("msc_layernorm_bwd_workspace_bytes", (b1 - b0) * T, D)) for _, b0, b1, ci in chains]
+    def each(fn):
+        for strm, b0, b1, ci in chains:
+            fn(strm, slice(b0 * T, b1 * T), slice(b0 * h, b1 * h), b1 - b0, ci)
+    def wgrad(xf, df, w, b):
+        # ONE weight (+ bias) gradient over the whole batch on the side stream, which waits for both chains
+        N, K = w.shape
+        wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
+        rt.call_side("msc_linear_wgrad", xf, df, w.g, b.g, rt.workspace("wgrad", wsb, per_stream=False), wsb, M, N, K, rt.accumulate, rt.dt)
+    def ln_sum(k, g, b):
+        if b.off == g.off + D:
+            rt.call_side("msc_add2_f32", lnt[0][k], lnt[1][k], g.g, 2 * D, rt.accumulate)
+        else:
+            rt.call_side("msc_add2_f32", lnt[0][k][:D], lnt[1][k][:D], g.g, D, rt.accumulate)
+            rt.call_side("msc_add2_f32", lnt[0][k][D:], lnt[1][k][D:], b.g, D, rt.accumulate)
+    rt.side_also_waits = (s2, ev_bs)
+    try:
+        wgrad(u, dx2, p["fc2w"], p["fc2b"])
+        # fc2's dgrad epilogue applies GELU' (from the saved pre-activation)
+        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dx2[r], p["fc2w"].t, upre[r], L.ACT_GELU, None, dpre[r], nb * T, D, Fh, rt.dt, c))
+        wgrad(h2, dpre, p["fc1w"], p["fc1b"])
+        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dpre[r], p["fc1w"].t, None, L.ACT_NONE, None, dh2[r], nb * T, Fh, D, rt.dt, c))
+        each(lambda c, r, bh, nb, ci: L.call("msc_layernorm_bwd", dh2[r], x1[r], st[2][r], st[3][r], p["ln2g"].p, dx2[r], dx1[r], lnt[ci][1][:D],
+                                             lnt[ci][1][D:], lnws[ci], nb * T, D, 0, rt.dt, c))
+        wgrad(o, dx1, p["projw"], p["projb"])
+        ln_sum(1, p["ln2g"], p["ln2b"])
+        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dx1[r], p["projw"].t, None, L.ACT_NONE, None, do[r], nb * T, D, D, rt.dt, c))
+        each(lambda c, r, bh, nb, ci: L.call("msc_attention_bwd", qkv[r], o[r], do[r], lse[bh], delta[bh], dqkv[r], nb, T, h, hd, scale, rt.dt, c))
+        wgrad(h1, dqkv, p["qkvw"], p["qkvb"])
+        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dqkv[r], p["qkvw"].t, None, L.ACT_NONE, None, dh1[r], nb * T, 3 * D, D, rt.dt, c))
+        each(lambda c, r, bh, nb, ci: L.call("msc_layernorm_bwd", dh1[r], x2d[r], st[0][r], st[1][r], p["ln1g"].p, dx1[r], dx[r], lnt[ci][0][:D],
+                                             lnt[ci][0][D:], lnws[ci], nb * T, D, 0, rt.dt, c))
+        ln_sum(0, p["ln1g"], p["ln1b"])
+    finally:
+        rt.side_also_waits = None
+    if p.get("first", True):                                            # the token gradient is consumed on the main stream
+        L.call("msc_stream_wait_stream", main, s2, ev_ba)
+    # everything the second chain reads must outlive its kernels: released with the side stream's operands at join_side()
+    (rt.capture_keep if torch.cuda.is_current_stream_capturing() else rt._side_keep).append(
+        (x2d, st, h1, qkv, lse, o, x1, h2, upre, u, dx2, dpre, dh2, dx1, do, dqkv, dh1, delta, lnt))
+    return dx.view(B, T, D), None, None, None
+
+
 class FusionLayerFn(torch.autograd.Function):
     """One pre-LN transformer block as ONE autograd node (LN -> QKV -> attention -> proj(+x) -> LN -> FFN(+x))."""
 
@@ -455,6 +560,9 @@ class FusionLayerFn(torch.autograd.Function):
     def forward(ctx, x, rt, p, h):
         B, T, D = x.shape
         hd = D // h
+        if _two_chains_ok(rt, B, T, hd):
+            return _fusion_fwd_two_chains(ctx, x, rt, p, h)
+        ctx.two = False
         x2d = x.reshape(B * T, D)
         h1, mu1, rs1 = layernorm_fwd(rt, x2d, p["ln1g"], p["ln1b"])
         qkv, _ = linear_fwd(rt, h1, p["qkvw"], p["qkvb"])
@@ -469,6 +577,8 @@ class FusionLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.two:
+            return _fusion_bwd_two_chains(ctx, dy)
         rt, p, h, (B, T, D) = ctx.cfg
         hd = D // h
         x2d, mu1, rs1, h1, qkv, P, o, x1, mu2, rs2, h2, upre, u = ctx.saved_tensors

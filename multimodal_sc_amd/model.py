@@ -279,7 +279,8 @@ class MultimodalSC:
             p = {"ln1g": P[f"{pre}.ln1.weight"], "ln1b": P[f"{pre}.ln1.bias"], "qkvw": P[f"{pre}.attn.qkv.weight"],
                  "qkvb": P[f"{pre}.attn.qkv.bias"], "projw": P[f"{pre}.attn.proj.weight"], "projb": P[f"{pre}.attn.proj.bias"],
                  "ln2g": P[f"{pre}.ln2.weight"], "ln2b": P[f"{pre}.ln2.bias"], "fc1w": P[f"{pre}.mlp.fc1.weight"],
-                 "fc1b": P[f"{pre}.mlp.fc1.bias"], "fc2w": P[f"{pre}.mlp.fc2.weight"], "fc2b": P[f"{pre}.mlp.fc2.bias"]}
+                 "fc1b": P[f"{pre}.mlp.fc1.bias"], "fc2w": P[f"{pre}.mlp.fc2.weight"], "fc2b": P[f"{pre}.mlp.fc2.bias"],
+                 "first": i == 0, "last": i == cfg.n_layers - 1}      # (where the two half-batch chains meet the main stream)
             x = F.FusionLayerFn.apply(x, rt, p, cfg.n_heads)
         return F.LayerNorm.apply(x, rt, P["fusion.ln_f.weight"], P["fusion.ln_f.bias"])
 

@@ -43,6 +43,7 @@ class Runtime:
         self._dev_index = self.device.index if self.device.index is not None else 0
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
+        self.side_also_waits = None  # (raw stream, event): call_side() also orders the side stream behind that stream
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
         self.host_counters = True    # step / noise-draw numbers as host arguments; Trainer turns it off for hipGraph replay,
                                      # where they must be device-side counters (one tiny kernel each per step)
@@ -120,6 +121,8 @@ class Runtime:
                 raise RuntimeError("msc_event_create failed")
         # side stream waits for everything enqueued so far on the launching stream (one reusable event, one C call)
         L.call("msc_stream_wait_stream", self._side_raw, _raw_stream(self._dev_index), self._side_event)
+        if self.side_also_waits is not None:      # operands produced on a second chain's stream (raw handle, event)
+            L.call("msc_stream_wait_stream", self._side_raw, self.side_also_waits[0], self.side_also_waits[1])
         rc = L.call(name, *args, self._side_raw)
         # The operands are read on the side stream but owned (for the caching allocator) by the launching stream: keep
         # them alive until join_side() has ordered the launching streams behind the side stream.  Cheaper than
@@ -127,6 +130,20 @@ class Runtime:
         (self.capture_keep if torch.cuda.is_current_stream_capturing() else self._side_keep).append(args)
         self._side_dirty = True
         return rc
+
+    # ---- second chain (FusionLayerFn): half of the batch runs on the BEV-branch stream, idle during the fusion
+    def chain_b(self):
+        """(raw handle of the BEV-branch stream, event main->b, event b->main, event b->side), created on first use"""
+        if getattr(self, "_chain", None) is None:
+            s2 = self.branch_stream()
+            evs = [L.query("msc_event_create") for _ in range(3)]
+            if not all(evs):
+                raise RuntimeError("msc_event_create failed")
+            self._chain = (s2.cuda_stream, *evs)
+        return self._chain
+
+    def call_on(self, raw_stream, name, *args):
+        return L.call(name, *args, raw_stream)
 
     def _make_side_stream(self):
         """The side stream runs at the LOWEST HIP priority: its kernels fill CUs the critical chain leaves idle instead
