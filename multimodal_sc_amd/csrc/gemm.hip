@@ -1122,7 +1122,7 @@ extern "C" int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out,
 // reduced over the K slices by extra blocks of the reduce launch
 static int finish_wgrad(GemmParams& p, float* dw, float* db, float* ws, int64_t ws_bytes, long reduce_len, int accumulate,
                         int dtype, hipStream_t st, int (*launch)(const GemmParams&, int, int, hipStream_t), int kstep_bytes) {
-  const mscplan::WgradSplit w = mscplan::wgrad_split(p.M, p.N, reduce_len, kstep_bytes / esize(dtype));
+  const mscplan::WgradSplit w = mscplan::wgrad_split(p.M, p.N, reduce_len, kstep_bytes / esize(dtype), kstep_bytes == 64 /* gathered conv wgrad */);
   const int ns = w.ns;
   if ((int64_t)ns * p.M * (p.N + 1) * 4 > ws_bytes || !ws) return MSC_ERR_BAD_ARG;
   if (((long)p.M * p.N) % 4 || (db && p.M % 4)) return MSC_ERR_BAD_ARG;

@@ -114,14 +114,14 @@ static inline ConvSplit conv_split(long M, long N, long k_len, int dtype_is_f32)
 // split-K of the weight-gradient GEMMs (output rows_out x cols_out, reduction over reduce_len pixels / tokens)
 static inline int plan_split(long rows_out, long cols_out, long reduce_len) {
   const long tiles = cdivl(rows_out, 128) * cdivl(cols_out, cols_out <= 64 ? 64 : 128);
-  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~768 workgroups measured best
+  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~640 workgroups measured best
   // (fewer: underfilled when the main stream idles; more: fp32 slab traffic = nsplit x output).  Same-box sweep of the step
-  // at the end of round 2 (XCD pinning really applied): 384: +0.06 ms, 512: 0, 768: -0.07, 1024 / 1536 / 2048: -0.05.
+  // at the end of round 2 (XCD pinning really applied, fusion as two chains): 384: +0.09 ms, 512: +0.05, 640: 0, 768: +0.07.
   static long target = 0;
   if (!target) {
     const char* e = getenv("MSC_WGRAD_BLOCKS");   // tuning knob (A/B runs)
-    target = e ? atol(e) : 768;
-    if (target < 1) target = 768;
+    target = e ? atol(e) : 640;
+    if (target < 1) target = 640;
   }
   long want = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
   long cap = reduce_len / 1024;
@@ -145,7 +145,7 @@ static inline int64_t wgrad_workspace_bytes(long rows_out, long cols_out, long r
 
 struct WgradSplit { int ns, tps, xcd_split; int64_t ws_bytes; };
 // kt = reduction elements per K step of the kernel variant that runs the launch
-static inline WgradSplit wgrad_split(long rows_out, long cols_out, long reduce_len, int kt) {
+static inline WgradSplit wgrad_split(long rows_out, long cols_out, long reduce_len, int kt, bool gathered = false) {
   const long nk = cdivl(reduce_len, kt);
   const int planned = plan_split(rows_out, cols_out, reduce_len);
   WgradSplit w;
@@ -161,9 +161,10 @@ static inline WgradSplit wgrad_split(long rows_out, long cols_out, long reduce_l
     }
   }
   // measured (tools/gemm_bench.py, MSC_WGRAD_XCD_SPLIT=0/1): -8..-17 % where a slice has few tiles or many K steps (layer 1/2, BEV,
-  // qkv), +15 % on layer 3 (36 tiles x 25 steps per slice) — short slices of many tiles stay on the plain mapping
+  // qkv), +15 % on layer 3's gathered conv weight gradient (36 tiles x 25 steps per slice) — short gathered slices of many tiles
+  // stay on the plain mapping; the dense (linear) weight gradients are always pinned (in the step: same time, 2.6 GB less L2-miss traffic)
   const long tiles = cdivl(rows_out, 128) * cdivl(cols_out, cols_out <= 64 ? 64 : 128);
-  w.xcd_split = (xs && w.ns >= 8 && w.ns % 8 == 0 && !(tiles > 32 && w.tps < 32)) ? 1 : 0;
+  w.xcd_split = (xs && w.ns >= 8 && w.ns % 8 == 0 && !(gathered && tiles > 32 && w.tps < 32)) ? 1 : 0;
   w.ws_bytes = (int64_t)planned * rows_out * (cols_out + 1) * 4;
   return w;
 }
