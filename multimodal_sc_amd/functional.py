@@ -469,24 +469,40 @@ def _fusion_fwd_two_chains(ctx, x, rt, p, h):
     h1, qkv, o, x1, h2 = rt.empty(M, D), rt.empty(M, 3 * D), rt.empty(M, D), rt.empty(M, D), rt.empty(M, D)
     upre, u, x2 = rt.empty(M, Fh), rt.empty(M, Fh), rt.empty(M, D)
     st = rt.f32(4, M)                                              # mu1, rs1, mu2, rs2
-    lse = rt.f32(B * h, L.query("msc_attention_tpad", T))
+    Tpad = L.query("msc_attention_tpad", T)
+    lse = rt.f32(B * h, Tpad)
     scale = 1.0 / math.sqrt(hd)
-    if p.get("first", True):                                            # the tokens were assembled on the main stream
+    if p.get("first", True):                                      # the tokens were assembled on the main stream
         L.call("msc_stream_wait_stream", s2, main, ev_ab)
+    # Raw device addresses of the chains' row ranges (plain integer arithmetic: slicing ~60 tensor views per layer costs the host
+    # more than the launches themselves, and the host paces the launch-dense fusion backward)
+    es = x2d.element_size()
+    a_x, a_h1, a_qkv, a_o, a_x1, a_h2 = x2d.data_ptr(), h1.data_ptr(), qkv.data_ptr(), o.data_ptr(), x1.data_ptr(), h2.data_ptr()
+    a_upre, a_u, a_x2, a_st, a_lse = upre.data_ptr(), u.data_ptr(), x2.data_ptr(), st.data_ptr(), lse.data_ptr()
+    ln1g, ln1b, ln2g, ln2b = p["ln1g"].p.data_ptr(), p["ln1b"].p.data_ptr(), p["ln2g"].p.data_ptr(), p["ln2b"].p.data_ptr()
+    wq, bq, wp, bp = p["qkvw"].c.data_ptr(), p["qkvb"].p.data_ptr(), p["projw"].c.data_ptr(), p["projb"].p.data_ptr()
+    w1, b1, w2, b2 = p["fc1w"].c.data_ptr(), p["fc1b"].p.data_ptr(), p["fc2w"].c.data_ptr(), p["fc2b"].p.data_ptr()
     Bh = B // 2
-    chains = ((main, 0, Bh), (s2, Bh, B))
+    # (stream, first row, rows, first (frame, head) row of lse, frames)
+    chains = ((main, 0, Bh * T, 0, Bh), (s2, Bh * T, (B - Bh) * T, Bh * h, B - Bh))
+    call, dt = L.call, rt.dt
+    rD, r3D, rF = D * es, 3 * D * es, Fh * es
     # the two chains' launches are enqueued alternately, kernel by kernel
-    def each(fn):
-        for strm, b0, b1 in chains:
-            fn(strm, slice(b0 * T, b1 * T), slice(b0 * h, b1 * h), b1 - b0)
-    each(lambda c, r, bh, nb: L.call("msc_layernorm_fwd", x2d[r], p["ln1g"].p, p["ln1b"].p, h1[r], st[0][r], st[1][r], nb * T, D, LN_EPS, rt.dt, c))
-    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", h1[r], p["qkvw"].c, p["qkvb"].p, None, qkv[r], None, nb * T, 3 * D, D, L.ACT_NONE, rt.dt, c))
-    each(lambda c, r, bh, nb: L.call("msc_attention_fwd", qkv[r], o[r], lse[bh], nb, T, h, hd, scale, rt.dt, c))
-    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", o[r], p["projw"].c, p["projb"].p, x2d[r], x1[r], None, nb * T, D, D, L.ACT_NONE, rt.dt, c))
-    each(lambda c, r, bh, nb: L.call("msc_layernorm_fwd", x1[r], p["ln2g"].p, p["ln2b"].p, h2[r], st[2][r], st[3][r], nb * T, D, LN_EPS, rt.dt, c))
-    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", h2[r], p["fc1w"].c, p["fc1b"].p, None, u[r], upre[r], nb * T, Fh, D, L.ACT_GELU, rt.dt, c))
-    each(lambda c, r, bh, nb: L.call("msc_linear_fwd", u[r], p["fc2w"].c, p["fc2b"].p, x1[r], x2[r], None, nb * T, D, Fh, L.ACT_NONE, rt.dt, c))
-    if p.get("last", True):                                             # the final LayerNorm reads the whole batch on the main stream
+    for c, r0, n, _, _ in chains:
+        call("msc_layernorm_fwd", a_x + r0 * rD, ln1g, ln1b, a_h1 + r0 * rD, a_st + r0 * 4, a_st + (M + r0) * 4, n, D, LN_EPS, dt, c)
+    for c, r0, n, _, _ in chains:
+        call("msc_linear_fwd", a_h1 + r0 * rD, wq, bq, None, a_qkv + r0 * r3D, None, n, 3 * D, D, L.ACT_NONE, dt, c)
+    for c, r0, n, l0, nb in chains:
+        call("msc_attention_fwd", a_qkv + r0 * r3D, a_o + r0 * rD, a_lse + l0 * Tpad * 4, nb, T, h, hd, scale, dt, c)
+    for c, r0, n, _, _ in chains:
+        call("msc_linear_fwd", a_o + r0 * rD, wp, bp, a_x + r0 * rD, a_x1 + r0 * rD, None, n, D, D, L.ACT_NONE, dt, c)
+    for c, r0, n, _, _ in chains:
+        call("msc_layernorm_fwd", a_x1 + r0 * rD, ln2g, ln2b, a_h2 + r0 * rD, a_st + (2 * M + r0) * 4, a_st + (3 * M + r0) * 4, n, D, LN_EPS, dt, c)
+    for c, r0, n, _, _ in chains:
+        call("msc_linear_fwd", a_h2 + r0 * rD, w1, b1, None, a_u + r0 * rF, a_upre + r0 * rF, n, Fh, D, L.ACT_GELU, dt, c)
+    for c, r0, n, _, _ in chains:
+        call("msc_linear_fwd", a_u + r0 * rF, w2, b2, a_x1 + r0 * rD, a_x2 + r0 * rD, None, n, D, Fh, L.ACT_NONE, dt, c)
+    if p.get("last", True):                                       # the final LayerNorm reads the whole batch on the main stream
         L.call("msc_stream_wait_stream", main, s2, ev_ba)
     ctx.save_for_backward(x2d, st, h1, qkv, lse, o, x1, h2, upre, u)
     ctx.cfg = (rt, p, h, (B, T, D))
@@ -504,48 +520,69 @@ def _fusion_bwd_two_chains(ctx, dy):
     dpre, dh2, dx1, do = rt.empty(M, Fh), rt.empty(M, D), rt.empty(M, D), rt.empty(M, D)
     dqkv, dh1, dx = rt.empty(M, 3 * D), rt.empty(M, D), rt.empty(M, D)
     delta = rt.f32(*lse.shape)
+    Tpad = lse.shape[1]
     lnt = rt.f32(2, 2, 2 * D)                                      # [chain][ln1 | ln2][dgamma | dbeta]
     scale = 1.0 / math.sqrt(hd)
-    if p.get("last", True):                                             # dy comes from the final LayerNorm's backward on the main stream
+    if p.get("last", True):                                       # dy comes from the final LayerNorm's backward on the main stream
         L.call("msc_stream_wait_stream", s2, main, ev_ab)
     Bh = B // 2
-    chains = ((main, 0, Bh, 0), (s2, Bh, B, 1))
-    lnws = [rt.workspace(f"ln_bwd_chain{ci}", L.query("msc_layernorm_bwd_workspace_bytes", (b1 - b0) * T, D)) for _, b0, b1, ci in chains]
-    def each(fn):
-        for strm, b0, b1, ci in chains:
-            fn(strm, slice(b0 * T, b1 * T), slice(b0 * h, b1 * h), b1 - b0, ci)
+    chains = ((main, 0, Bh * T, 0, Bh, 0), (s2, Bh * T, (B - Bh) * T, Bh * h, B - Bh, 1))
+    lnws = [rt.workspace(f"ln_bwd_chain{ci}", L.query("msc_layernorm_bwd_workspace_bytes", n, D)).data_ptr() for _, _, n, _, _, ci in chains]
+    es = x2d.element_size()
+    rD, r3D, rF = D * es, 3 * D * es, Fh * es
+    a_x, a_h1, a_qkv, a_o, a_x1, a_h2 = x2d.data_ptr(), h1.data_ptr(), qkv.data_ptr(), o.data_ptr(), x1.data_ptr(), h2.data_ptr()
+    a_upre, a_st, a_lse, a_delta, a_lnt = upre.data_ptr(), st.data_ptr(), lse.data_ptr(), delta.data_ptr(), lnt.data_ptr()
+    a_dx2, a_dpre, a_dh2, a_dx1, a_do = dx2.data_ptr(), dpre.data_ptr(), dh2.data_ptr(), dx1.data_ptr(), do.data_ptr()
+    a_dqkv, a_dh1, a_dx = dqkv.data_ptr(), dh1.data_ptr(), dx.data_ptr()
+    ln1g, ln2g = p["ln1g"].p.data_ptr(), p["ln2g"].p.data_ptr()
+    tq, tp, t1, t2 = p["qkvw"].t.data_ptr(), p["projw"].t.data_ptr(), p["fc1w"].t.data_ptr(), p["fc2w"].t.data_ptr()
+    call, dt = L.call, rt.dt
+
     def wgrad(xf, df, w, b):
         # ONE weight (+ bias) gradient over the whole batch on the side stream, which waits for both chains
         N, K = w.shape
         wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)
         rt.call_side("msc_linear_wgrad", xf, df, w.g, b.g, rt.workspace("wgrad", wsb, per_stream=False), wsb, M, N, K, rt.accumulate, rt.dt)
+
     def ln_sum(k, g, b):
         if b.off == g.off + D:
             rt.call_side("msc_add2_f32", lnt[0][k], lnt[1][k], g.g, 2 * D, rt.accumulate)
         else:
             rt.call_side("msc_add2_f32", lnt[0][k][:D], lnt[1][k][:D], g.g, D, rt.accumulate)
             rt.call_side("msc_add2_f32", lnt[0][k][D:], lnt[1][k][D:], b.g, D, rt.accumulate)
+
+    def lnt_ptr(ci, k, half):                                       # lnt[ci][k][half * D:]
+        return a_lnt + ((ci * 2 + k) * 2 * D + half * D) * 4
+
     rt.side_also_waits = (s2, ev_bs)
     try:
         wgrad(u, dx2, p["fc2w"], p["fc2b"])
         # fc2's dgrad epilogue applies GELU' (from the saved pre-activation)
-        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dx2[r], p["fc2w"].t, upre[r], L.ACT_GELU, None, dpre[r], nb * T, D, Fh, rt.dt, c))
+        for c, r0, n, _, _, _ in chains:
+            call("msc_linear_dgrad", a_dx2 + r0 * rD, t2, a_upre + r0 * rF, L.ACT_GELU, None, a_dpre + r0 * rF, n, D, Fh, dt, c)
         wgrad(h2, dpre, p["fc1w"], p["fc1b"])
-        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dpre[r], p["fc1w"].t, None, L.ACT_NONE, None, dh2[r], nb * T, Fh, D, rt.dt, c))
-        each(lambda c, r, bh, nb, ci: L.call("msc_layernorm_bwd", dh2[r], x1[r], st[2][r], st[3][r], p["ln2g"].p, dx2[r], dx1[r], lnt[ci][1][:D],
-                                             lnt[ci][1][D:], lnws[ci], nb * T, D, 0, rt.dt, c))
+        for c, r0, n, _, _, _ in chains:
+            call("msc_linear_dgrad", a_dpre + r0 * rF, t1, None, L.ACT_NONE, None, a_dh2 + r0 * rD, n, Fh, D, dt, c)
+        for c, r0, n, _, _, ci in chains:
+            call("msc_layernorm_bwd", a_dh2 + r0 * rD, a_x1 + r0 * rD, a_st + (2 * M + r0) * 4, a_st + (3 * M + r0) * 4, ln2g, a_dx2 + r0 * rD,
+                 a_dx1 + r0 * rD, lnt_ptr(ci, 1, 0), lnt_ptr(ci, 1, 1), lnws[ci], n, D, 0, dt, c)
         wgrad(o, dx1, p["projw"], p["projb"])
         ln_sum(1, p["ln2g"], p["ln2b"])
-        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dx1[r], p["projw"].t, None, L.ACT_NONE, None, do[r], nb * T, D, D, rt.dt, c))
-        each(lambda c, r, bh, nb, ci: L.call("msc_attention_bwd", qkv[r], o[r], do[r], lse[bh], delta[bh], dqkv[r], nb, T, h, hd, scale, rt.dt, c))
+        for c, r0, n, _, _, _ in chains:
+            call("msc_linear_dgrad", a_dx1 + r0 * rD, tp, None, L.ACT_NONE, None, a_do + r0 * rD, n, D, D, dt, c)
+        for c, r0, n, l0, nb, _ in chains:
+            call("msc_attention_bwd", a_qkv + r0 * r3D, a_o + r0 * rD, a_do + r0 * rD, a_lse + l0 * Tpad * 4, a_delta + l0 * Tpad * 4,
+                 a_dqkv + r0 * r3D, nb, T, h, hd, scale, dt, c)
         wgrad(h1, dqkv, p["qkvw"], p["qkvb"])
-        each(lambda c, r, bh, nb, ci: L.call("msc_linear_dgrad", dqkv[r], p["qkvw"].t, None, L.ACT_NONE, None, dh1[r], nb * T, 3 * D, D, rt.dt, c))
-        each(lambda c, r, bh, nb, ci: L.call("msc_layernorm_bwd", dh1[r], x2d[r], st[0][r], st[1][r], p["ln1g"].p, dx1[r], dx[r], lnt[ci][0][:D],
-                                             lnt[ci][0][D:], lnws[ci], nb * T, D, 0, rt.dt, c))
+        for c, r0, n, _, _, _ in chains:
+            call("msc_linear_dgrad", a_dqkv + r0 * r3D, tq, None, L.ACT_NONE, None, a_dh1 + r0 * rD, n, 3 * D, D, dt, c)
+        for c, r0, n, _, _, ci in chains:
+            call("msc_layernorm_bwd", a_dh1 + r0 * rD, a_x + r0 * rD, a_st + r0 * 4, a_st + (M + r0) * 4, ln1g, a_dx1 + r0 * rD, a_dx + r0 * rD,
+                 lnt_ptr(ci, 0, 0), lnt_ptr(ci, 0, 1), lnws[ci], n, D, 0, dt, c)
         ln_sum(0, p["ln1g"], p["ln1b"])
     finally:
         rt.side_also_waits = None
-    if p.get("first", True):                                            # the token gradient is consumed on the main stream
+    if p.get("first", True):                                      # the token gradient is consumed on the main stream
         L.call("msc_stream_wait_stream", main, s2, ev_ba)
     # everything the second chain reads must outlive its kernels: released with the side stream's operands at join_side()
     (rt.capture_keep if torch.cuda.is_current_stream_capturing() else rt._side_keep).append(
