@@ -666,6 +666,19 @@ def test_pillar_edge_cases(rts, case):
             assert rel < 2e-3, f"{case} {name}: relative Frobenius error {rel:.3e}"
 
 
+def test_add2_f32(rts):
+    """out = (accumulate ? out : 0) + (a + b): the fixed-order sum of the two fusion chains' LayerNorm parameter gradients"""
+    rt = rts["bf16"]
+    a, b, o = rnd(1024, seed=1).to(rt.device), rnd(1024, seed=2).to(rt.device), rnd(1024, seed=3).to(rt.device)
+    o0 = o.clone()
+    rt.call("msc_add2_f32", a, b, o, 1024, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o0 + (a + b))
+    rt.call("msc_add2_f32", a, b, o, 1024, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(o, a + b)
+
+
 # ------------------------------------------------------------------------------------------------ heads / losses
 def test_argmax_ties_bit_exact(rts):
     for dtype in DTYPES:

@@ -277,6 +277,32 @@ def test_bf16_end_to_end_parity_c3(cuda):
     assert all(a > b - 0.02 for a, b, _ in rows), [r for r in rows if r[0] <= r[1] - 0.02]
 
 
+def test_fusion_two_chains_equal_one_chain(cuda, monkeypatch):
+    """The fusion layers run the two halves of the batch as two chains of launches on two streams.  Every kernel of a layer is
+    per-sample and the weight gradients still run once over the whole batch, so against the one-chain schedule the outputs and
+    every gradient are BIT-identical, except the LayerNorm parameter gradients, whose two half sums are added in a different order."""
+    from multimodal_sc_amd import functional as F
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from oracle import model as O
+    res = {}
+    for two in (True, False):
+        monkeypatch.setattr(F, "_FUSION_CHAINS", two)
+        m = MultimodalSC(named_config("C3"), dtype="bf16", device="cuda:0", seed=3)
+        gb = _to(m.rt.device, O.synthetic_batch(O.named_config("C3"), 5, seed=5))      # odd batch: chains of 2 and 3 frames
+        out = m(gb["image"], gb.get("points"), gb.get("state"), gb["snr_db"], gb["noise"], gb["fading"])
+        m.loss_and_grads(out, gb["image"], gb["ppo"])
+        torch.cuda.synchronize()
+        res[two] = (out["head"].clone(), out["patches"].clone(), m.params.G.clone(), m)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    m = res[True][3]
+    for name, ref in m.params.refs.items():
+        a, b = res[True][2][ref.off:ref.off + ref.numel], res[False][2][ref.off:ref.off + ref.numel]
+        if name.startswith("fusion.layers.") and (".ln1." in name or ".ln2." in name):
+            assert (a - b).abs().max().item() <= 1e-5 * max(1e-6, b.abs().max().item()), name
+        else:
+            assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("name,B", [("C3", 2), ("C3", 64), ("C1", 64), ("C2", 64)])
 def test_determinism_bitwise(cuda, name, B):
     """run the same step twice: every output and every gradient must be bit-identical (no float atomics anywhere) — also
