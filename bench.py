@@ -36,7 +36,7 @@ def gemm_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_hbm_bytes_per_gemm_launch():
+def pmc_hbm_bytes_per_gemm_launch(n_launches_instrumented=0):
     """HBM bytes per launch of the contraction kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, separate passes over this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM;
     tools/pmc_hbm_summary.py).  Hardware counters cannot be read from inside the timed process, so the figure comes from the
@@ -55,6 +55,13 @@ def pmc_hbm_bytes_per_gemm_launch():
         if "gemm_kernel<unsigned short" in r["kernel"]:
             b += float(r["fetch_bytes_corrected_x2"]) + float(r["write_bytes"])
             n += int(r["calls"])
+    # The profiled run is the normal multi-stream step, where the fusion layers launch every dense GEMM twice (two half-batch
+    # chains); the roofline line counts launches of the single-chain instrumented pass.  With the number of profiled steps in
+    # the sidecar the figure is bytes per STEP divided by that pass's launch count (so it compares with
+    # algorithmic_bytes_per_launch); without it, bytes per profiled launch.
+    steps = json.load(open(meta)).get("steps_profiled")
+    if steps and n_launches_instrumented:
+        return b / steps / n_launches_instrumented, PMC_HBM_SUMMARY + " (committed profile of this source; bytes per step / launches of the instrumented pass)"
     return (b / n if n else None), PMC_HBM_SUMMARY + " (committed profile of this source)"
 
 
@@ -288,7 +295,7 @@ def main():
                 n_gemm += 1
         rt.profile = None
         achieved = gemm_f / (gemm_t * 1e-3) / 1e12
-        traffic, traffic_src = pmc_hbm_bytes_per_gemm_launch()
+        traffic, traffic_src = pmc_hbm_bytes_per_gemm_launch(n_gemm)
         result["build_id"] = __import__("multimodal_sc_amd.lib", fromlist=["lib"]).lib.msc_build_id().decode()
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",

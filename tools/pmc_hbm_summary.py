@@ -34,5 +34,6 @@ if len(sys.argv) > 3:
     for f in ("gemm.hip", "gemm_plan.h"):
         h.update(open(os.path.join(root, "multimodal_sc_amd", "csrc", f), "rb").read())
     sha = h.hexdigest()[:16]
-    json.dump({"gemm_hip_sha256_16": sha, "fetch_csv": os.path.basename(sys.argv[1]), "write_csv": os.path.basename(sys.argv[2])},
-              open(sys.argv[3] + ".meta.json", "w"))
+    # steps the profiled command ran (warm-up + timed): PMC_STEPS, default 4 = `bench.py --steps 3 --warmup 1` of tools/round_profile.sh
+    json.dump({"gemm_hip_sha256_16": sha, "fetch_csv": os.path.basename(sys.argv[1]), "write_csv": os.path.basename(sys.argv[2]),
+               "steps_profiled": int(os.environ.get("PMC_STEPS", "4"))}, open(sys.argv[3] + ".meta.json", "w"))
