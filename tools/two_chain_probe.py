@@ -44,3 +44,23 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 for name, fn in (("one chain, full batch", run_full), ("two half-batch chains, two streams", run_split), ("... launches interleaved", run_split_interleaved)):
     print(f"{name:40s} {timeit(fn):7.1f} us per layer-forward of linears")
+
+# ---- same question for the camera trunk's convolutions (layer 1: 64->64 3x3 at 56x56; layer 3: 256->256 at 14x14), forward GEMMs only
+def conv_chain(B, H, C, st, bufs):
+    x, w, y, part = bufs
+    Ho = H
+    L.call("msc_conv2d_fwd", x, w, y, part, B, H, H, C, C, 3, 3, 1, 1, None, 0, rt.dt, st.cuda_stream)
+
+
+def mkconv(B, H, C):
+    x = (torch.randn(B, H, H, C, device=dev) * 0.5).to(torch.bfloat16); w = (torch.randn(C, 3, 3, C, device=dev) * 0.05).to(torch.bfloat16)
+    y = torch.empty(B, H, H, C, device=dev, dtype=torch.bfloat16)
+    part = torch.empty(L.query("msc_conv2d_fwd_stat_rows", B * H * H, C, rt.dt) * 2 * C, device=dev)
+    return (x, w, y, part)
+
+
+for H, C in ((56, 64), (28, 128), (14, 256)):
+    full, ha, hb = mkconv(64, H, C), mkconv(32, H, C), mkconv(32, H, C)
+    one = lambda: [conv_chain(64, H, C, s1, full) for _ in range(4)]
+    two = lambda: [(conv_chain(32, H, C, s1, ha), conv_chain(32, H, C, s2, hb)) for _ in range(4)]
+    print(f"conv {C}->{C} 3x3 @{H}: 4 launches full batch {timeit(one):7.1f} us   two half-batch chains {timeit(two):7.1f} us")
