@@ -449,6 +449,7 @@ def attention_bwd(rt: Runtime, do, qkv, o, P, B, T, h, hd):
 
 
 _FUSION_CHAINS = os.environ.get("MSC_FUSION_CHAINS", "2") != "1"     # A/B knob: 1 = the whole batch as one chain of launches
+_CHAIN_MIN_ROWS = 0 if os.environ.get("MSC_FUSION_CHAINS") == "force" else 11264   # token rows (B*T) from which two chains pay
 
 
 def _two_chains_ok(rt: Runtime, B, T, hd):
@@ -457,7 +458,10 @@ def _two_chains_ok(rt: Runtime, B, T, hd):
     their load / MFMA / store phases in lock-step, two concurrent half-size launches interleave them (tools/two_chain_probe.py:
     the four forward linears of a layer 255 -> 207 us).  Weight gradients still run ONCE over the whole batch (the halves are
     row ranges of the same buffers)."""
-    return _FUSION_CHAINS and _FUSED_BIAS and B >= 2 and rt.branch_streams and rt.side_active() and fused_attention_ok(rt, T, hd)
+    # below ~36 frames of 306 tokens the half-size kernels are too short to pay for twice the launches (same box, one chain vs two:
+    # 16 frames 4.07 vs 6.03 ms, 32: 5.44 vs 5.58, 40: 6.17 vs 6.11, 48: 6.78 vs 6.67, 64: 8.10 vs 7.95); tests force it with MSC_FUSION_CHAINS=force
+    big = B * T >= _CHAIN_MIN_ROWS
+    return _FUSION_CHAINS and _FUSED_BIAS and B >= 2 and big and rt.branch_streams and rt.side_active() and fused_attention_ok(rt, T, hd)
 
 
 def _fusion_fwd_two_chains(ctx, x, rt, p, h):

@@ -285,6 +285,7 @@ def test_fusion_two_chains_equal_one_chain(cuda, monkeypatch):
     from multimodal_sc_amd.model import MultimodalSC, named_config
     from oracle import model as O
     res = {}
+    monkeypatch.setattr(F, "_CHAIN_MIN_ROWS", 0)          # (the default only splits batches of >= ~37 frames)
     for two in (True, False):
         monkeypatch.setattr(F, "_FUSION_CHAINS", two)
         m = MultimodalSC(named_config("C3"), dtype="bf16", device="cuda:0", seed=3)
@@ -366,9 +367,11 @@ def test_training_reduces_loss(cuda):
 def test_hipgraph_replay_matches_eager(cuda, monkeypatch):
     """Trainer.step captured into hipGraphs (opt-in, MSC_HIP_GRAPH=1: two eager warm-up steps, then replays) must leave
     bit-identical parameters to the eager launch path — same kernels, same order, step counter / noise seed read from device memory."""
+    from multimodal_sc_amd import functional as F
     from multimodal_sc_amd.model import MultimodalSC, named_config
     from multimodal_sc_amd.trainer import Trainer
     from oracle import model as O
+    monkeypatch.setattr(F, "_CHAIN_MIN_ROWS", 0)          # the fusion's two half-batch chains are part of what is captured
     res = {}
     for tag in ("0", "0b", "1"):
         mode = tag[0]
