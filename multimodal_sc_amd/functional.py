@@ -508,6 +508,12 @@ def _fusion_fwd_two_chains(ctx, x, rt, p, h):
         call("msc_linear_fwd", a_u + r0 * rF, w2, b2, a_x1 + r0 * rD, a_x2 + r0 * rD, None, n, D, Fh, L.ACT_NONE, dt, c)
     if p.get("last", True):                                       # the final LayerNorm reads the whole batch on the main stream
         L.call("msc_stream_wait_stream", main, s2, ev_ba)
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        # inference / rollout collection: nothing keeps these buffers alive for a backward, and the caching allocator would hand
+        # them back to the main stream while the second chain still uses them
+        s2t = rt.branch_stream()
+        for t in (x2d, st, h1, qkv, lse, o, x1, h2, upre, u, x2):
+            t.record_stream(s2t)
     ctx.save_for_backward(x2d, st, h1, qkv, lse, o, x1, h2, upre, u)
     ctx.cfg = (rt, p, h, (B, T, D))
     ctx.two = True

@@ -277,6 +277,25 @@ def test_bf16_end_to_end_parity_c3(cuda):
     assert all(a > b - 0.02 for a, b, _ in rows), [r for r in rows if r[0] <= r[1] - 0.02]
 
 
+def test_fusion_two_chains_no_grad_forward(cuda):
+    """inference / rollout forwards at a batch large enough for the two fusion chains (nothing is saved for a backward there: the
+    buffers the second chain uses are protected by record_stream) give the same outputs as the training-mode forward, repeatedly"""
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from oracle import model as O
+    m = MultimodalSC(named_config("C3"), dtype="bf16", device="cuda:0", seed=3)
+    gb = _to(m.rt.device, O.synthetic_batch(O.named_config("C3"), 48, seed=5))
+    args = (gb["image"], gb.get("points"), gb.get("state"), gb["snr_db"], gb["noise"], gb["fading"])
+    ref = m(*args)
+    ref = (ref["head"].clone(), ref["patches"].clone())
+    for _ in range(3):
+        with torch.no_grad():
+            out = m(*args)
+            junk = [torch.full((1 << 22,), float("nan"), device=m.rt.device) for _ in range(8)]     # churn the allocator
+        torch.cuda.synchronize()
+        assert torch.equal(out["head"], ref[0]) and torch.equal(out["patches"], ref[1])
+        del junk
+
+
 def test_fusion_two_chains_equal_one_chain(cuda, monkeypatch):
     """The fusion layers run the two halves of the batch as two chains of launches on two streams.  Every kernel of a layer is
     per-sample and the weight gradients still run once over the whole batch, so against the one-chain schedule the outputs and
