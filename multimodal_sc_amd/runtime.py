@@ -44,6 +44,7 @@ class Runtime:
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
         self.side_also_waits = None  # (raw stream, event): call_side() also orders the side stream behind that stream
+        self._chain = None           # chain_b(): raw BEV-branch stream + the three events of the fusion's second chain
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
         self.host_counters = True    # step / noise-draw numbers as host arguments; Trainer turns it off for hipGraph replay,
                                      # where they must be device-side counters (one tiny kernel each per step)
@@ -134,7 +135,7 @@ class Runtime:
     # ---- second chain (FusionLayerFn): half of the batch runs on the BEV-branch stream, idle during the fusion
     def chain_b(self):
         """(raw handle of the BEV-branch stream, event main->b, event b->main, event b->side), created on first use"""
-        if getattr(self, "_chain", None) is None:
+        if self._chain is None:
             s2 = self.branch_stream()
             evs = [L.query("msc_event_create") for _ in range(3)]
             if not all(evs):
