@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the multimodal semantic-communication training step on N MI355X GPUs.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+N>1: one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE set) this process IS a rank; started bare
+(`python bench.py --gpus 8`) it spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+process before anything touches the GPU, relays rank 0's JSON line and exits with the child's return code.
 
 A "step" = one forward + backward + gradient all-reduce + fused-Adam update over a batch of 64 synthetic frames PER
 GPU (weak scaling) of the workload BASELINE.json's metric is quoted on: camera 3x224x224 + 16384-point LiDAR cloud +
@@ -111,11 +114,12 @@ def gemm_bytes(name, s):
     return None
 
 
-def cpu_baseline(cfg_name, seconds_budget=25.0):
+def cpu_baseline(cfg_name, seconds_budget=60.0):
     """oracle fwd+bwd (fp32, all host threads) on a bounded sample of the same workload -> frames/s.
-    The batch is the largest of 64/32 whose measured step fits the time budget (a small batch cannot feed a many-core host,
-    which would understate the baseline): one probing step at 32 frames decides whether 64 fits; the reported rate is
-    the best batch's steady steps."""
+    Procedure (BASELINE.md "CPU-baseline plan"): 2 warm-up steps + 5 timed steps at one batch size, MEDIAN step time.
+    The batch is 32 frames when one probing step at 16 frames says 7 steps of 32 fit the time budget, else 16 (a small
+    batch cannot feed a many-core host, which would understate the baseline)."""
+    import statistics
     import torch
     from oracle import model as O
     cfg = O.named_config(cfg_name)
@@ -132,27 +136,26 @@ def cpu_baseline(cfg_name, seconds_budget=25.0):
             loss.backward()
         return step
 
-    t_start = time.time()
-    B = 32
+    B = 16
     step = make_step(B)
-    step()                                   # warm-up (allocator, thread pool)
+    step()                                   # allocator / thread-pool warm-up (not counted as one of the two below)
     t0 = time.time()
     step()
-    t32 = time.time() - t0
-    best = (B / t32, B, 1)
-    if 2 * t32 * 3 < seconds_budget - (time.time() - t_start):      # warm-up + 2 timed steps at 64 frames fit
-        B = 64
+    t16 = time.time() - t0
+    if 2.0 * t16 * 7 < seconds_budget:       # 2 warm-ups + 5 timed steps at 32 frames fit the budget
+        B = 32
         step = make_step(B)
+    n_warm, n_timed, times = 2, 5, []
+    for _ in range(n_warm):
         step()
-    n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t_start < seconds_budget and n < 4):
+    for _ in range(n_timed):
+        t0 = time.time()
         step()
-        n += 1
-    rate = B * n / (time.time() - t0)
-    if rate > best[0]:
-        best = (rate, B, n)
-    return {"value": best[0], "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/model.py fwd+bwd, config {cfg_name}, batch {best[1]} x {best[2]} timed steps, fp32, "
+        times.append(time.time() - t0)
+    med = statistics.median(times)
+    return {"value": B / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "step_s_median": med, "step_s_min": min(times), "step_s_max": max(times),
+            "sample": f"oracle/model.py fwd+bwd, config {cfg_name}, batch {B}: {n_warm} warm-up + {n_timed} timed steps, median, fp32, "
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} host cpus, no optimizer step"}
 
 
@@ -179,7 +182,53 @@ def allreduce_probe(model, trainer, dist, torch, reps=5):
     return out
 
 
-def main():
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start the N ranks ourselves.  Runs BEFORE anything in this process
+    touches the GPU (no torch.cuda call, no HIP call) and starts torch.distributed.run as a child — never an exec of this
+    process; stdout of the child (rank 0's JSON line) is relayed line by line, the child's return code is ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def selftest_ranks(args):
+    """--selftest-ranks: the launch path alone (rendezvous, a sum over ranks, one JSON line from rank 0) on the gloo backend,
+    no GPU and no model — what tests/test_bench_cpu.py drives through the self-spawn above."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, (world, args.gpus)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    if rank == world - 1 and os.environ.get("MSC_SELFTEST_EXIT"):     # (test hook: a failing rank must fail the parent)
+        return int(os.environ["MSC_SELFTEST_EXIT"])
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": float(t.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -189,7 +238,15 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="also time the step fed from a host-resident frame source (pinned ring + H2D staging)")
+    ap.add_argument("--selftest-ranks", action="store_true", help="launch-path self-test on gloo: no GPU, no model")
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    if args.selftest_ranks:
+        return selftest_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -200,7 +257,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # MSC_BENCH_BACKEND=gloo rehearses the N>1 code path on a one-GPU box (all ranks share cuda:0, gradients summed
     # through host memory); the driver's real runs use the default "nccl" = RCCL, one rank per GPU.
     backend = os.environ.get("MSC_BENCH_BACKEND", "nccl")
@@ -301,7 +358,11 @@ def main():
                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                               "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gemm_b / max(n_gemm, 1),
                               "kernel": "gemm_kernel<bf16,*>",
-                              "launches_per_step": n_gemm, "algorithmic_gflop_per_step": gemm_f / 1e9, "kernel_ms_per_step": gemm_t}
+                              "launches_per_step": n_gemm, "algorithmic_gflop_per_step": gemm_f / 1e9, "kernel_ms_per_step": gemm_t,
+                              # the same FLOPs over the WHOLE timed step (checkable against the driver's clock around the run):
+                              # what the step sees, with every other kernel, the stream overlap and the host loop included
+                              "whole_step_tflops": gemm_f / (result["ms_per_step"] * 1e-3) / 1e12,
+                              "whole_step_frac": gemm_f / (result["ms_per_step"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         result["breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -316,4 +377,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -79,13 +79,15 @@ int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_
  * pre-activation (needed by GELU/tanh backward).  bias,res,pre optional.  bias is fp32. */
 int msc_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, void* pre,
                    int M, int N, int K, int act, int dtype, void* stream);
-/* dx[M,K] = (dy[M,N] wt[K,N]^T) * act'(dact_ref[M,K])   (wt = w transposed, [K][N] row-major).
+/* dx[M,K] = (dy[M,N] wt[K,N]^T + res[M,K]) * act'(dact_ref[M,K])   (wt = w transposed, [K][N] row-major).
+ * res (optional, T): a gradient w.r.t. this layer's input arriving over another branch (a tensor with two consumers), summed here
+ * in fp32 before the one rounding of dx.
  * dact_ref/dact (optional): fused backward of the activation that FED this layer — dact_ref is that activation's
  * output (relu/tanh/sigmoid) or pre-activation (gelu); dx is then the gradient w.r.t. the previous layer's
  * pre-activation.  colsum_partial (optional): fp32 [msc_linear_dgrad_colsum_rows(M,K,dtype)][K] per-row-block column sums
  * of dx (= the previous layer's bias gradient after msc_colsum_finalize). */
 int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K, int dtype);
-int msc_linear_dgrad(const void* dy, const void* wt, const void* dact_ref, int dact, float* colsum_partial, void* dx,
+int msc_linear_dgrad(const void* dy, const void* wt, const void* res, const void* dact_ref, int dact, float* colsum_partial, void* dx,
                      int M, int N, int K, int dtype, void* stream);
 int msc_colsum_finalize(const float* partial, int nblk, int64_t cols, float* out, int accumulate, void* stream);
 /* dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db (optional, fp32 [N], N % 4 == 0) = column sums of dy = the bias gradient, produced by
@@ -229,7 +231,12 @@ int msc_pillar_bwd(const float* sorted_pts, const int32_t* cell_start, const flo
 
 /* ---------------------------------------------------------------------------------------------
  * Policy / value head, losses, attention softmax. */
+/* Action selection (integer outputs are bit-exact): order = value descending, index ascending on exact ties (0.0 == -0.0
+ * ties), NaN after everything else.  msc_topk_rows: out_idx int64 [rows][k], out_val fp32 [rows][k] (may be NULL), 1 <= k <= 8,
+ * k <= n <= 32; k = 1 gives msc_argmax_rows.  oracle: oracle/rl.py topk_rows (stable lexicographic sort). */
 int msc_argmax_rows(const void* x, int64_t* out, int64_t rows, int n, int64_t ld, int dtype, void* stream);
+int msc_topk_rows(const void* x, int64_t* out_idx, float* out_val, int64_t rows, int n, int k, int64_t ld, int dtype,
+                  void* stream);
 /* head: T [B][ld], cols 0..A-1 logits, col A value.  terms fp32[4] = total, policy, value, entropy. */
 int msc_ppo_loss(const void* head, const int64_t* actions, const float* old_logp, const float* adv,
                  const float* ret, float* terms, void* dhead, int B, int A, int ld, float clip_eps, float c_v,

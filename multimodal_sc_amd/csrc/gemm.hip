@@ -1264,14 +1264,14 @@ extern "C" int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K, int dtype) {
   return cdiv(M, tile_for(M, K, 1, OPM_DENSE_K, OPM_DENSE_K, dtype).bm);
 }
 
-extern "C" int msc_linear_dgrad(const void* dy, const void* wt, const void* dact_ref, int dact, float* colsum_partial, void* dx, int M,
+extern "C" int msc_linear_dgrad(const void* dy, const void* wt, const void* res, const void* dact_ref, int dact, float* colsum_partial, void* dx, int M,
                                 int N, int K, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && wt && dx && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(N % vec_of(dtype) == 0);
   if (!fits32((long)M * N, dtype) || !fits32((long)N * K, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
-  p.A = dy; p.B = wt; p.C = dx; p.dref = dact_ref; p.dact = dact; p.colsum = colsum_partial;
+  p.A = dy; p.B = wt; p.C = dx; p.res = res; p.dref = dact_ref; p.dact = dact; p.colsum = colsum_partial;
   p.M = M; p.N = K; p.K = N; p.lda = N; p.ldb = N; p.ldc = K;
   if (dact_ref || colsum_partial) return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K, true>(p, 1, dtype, (hipStream_t)stream);
   return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);

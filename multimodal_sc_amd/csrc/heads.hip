@@ -1,11 +1,19 @@
 // heads.hip — policy/value head selection + losses, reconstruction loss, attention softmax.
 //   msc_argmax_rows     : arg-max with lowest-index tie-break (bit-exact integer output)
+//   msc_topk_rows       : top-k action indices (k <= 8 of n <= 32), order (value desc, index asc); k = 1 == arg-max
 //   msc_ppo_loss        : PPO clipped surrogate + value + entropy, returns loss terms AND d/d(head output)
 //   msc_recon_loss      : MSE between sigmoid patch output and the NCHW image, per-sample SSE (-> PSNR) and gradient
 //   msc_unpatchify      : patches -> NCHW fp32 image
 //   msc_softmax_fwd/bwd : row softmax for the unfused attention path (fp32 scores in, T probabilities out)
 // Build-authored (the upstream reference has no code, SURVEY.md finding zero).
 #include "msc_common.h"
+
+// Order used by arg-max and top-k: value descending, index ascending on exact ties (0.0 == -0.0 is a tie), NaN after
+// everything else (also after -inf).  `a beats b` for a candidate at a HIGHER index than b, so ties keep the lower index.
+__device__ __forceinline__ bool rank_beats(float va, float vb) {
+  const bool na = va != va, nb = vb != vb;
+  return na != nb ? nb : va > vb;
+}
 
 template <typename T>
 __global__ void argmax_rows_kernel(const T* __restrict__ x, int64_t* __restrict__ out, long rows, int n, long ld) {
@@ -15,9 +23,35 @@ __global__ void argmax_rows_kernel(const T* __restrict__ x, int64_t* __restrict_
   int bi = 0;
   for (int j = 1; j < n; ++j) {
     const float v = msc_traits<T>::ld(x + r * ld + j);
-    if (v > best) { best = v; bi = j; }   // strict: the lowest index wins ties
+    if (rank_beats(v, best)) { best = v; bi = j; }   // strict: the lowest index wins ties
   }
   out[r] = bi;
+}
+
+// top-k by k selection passes over a row held in registers (n <= 32 action logits, k <= 8): pass p picks the best element
+// not picked yet; bit p of `taken` marks it.  One thread per row: B rows of 9-16 logits, pure latency.
+#define TOPK_MAX_N 32
+#define TOPK_MAX_K 8
+template <typename T>
+__global__ void topk_rows_kernel(const T* __restrict__ x, int64_t* __restrict__ out_idx, float* __restrict__ out_val, long rows,
+                                 int n, int k, long ld) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float v[TOPK_MAX_N];
+#pragma unroll
+  for (int j = 0; j < TOPK_MAX_N; ++j) v[j] = j < n ? msc_traits<T>::ld(x + r * ld + j) : 0.f;
+  uint32_t taken = 0;
+  for (int p = 0; p < k; ++p) {
+    int bi = -1;
+    float best = 0.f;
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX_N; ++j) {
+      if (j < n && !((taken >> j) & 1u) && (bi < 0 || rank_beats(v[j], best))) { best = v[j]; bi = j; }
+    }
+    taken |= 1u << bi;
+    out_idx[r * k + p] = bi;
+    if (out_val) out_val[r * k + p] = best;
+  }
 }
 
 // One block.  head: T [B][ld], cols 0..A-1 = logits, col A = value.
@@ -202,6 +236,19 @@ extern "C" int msc_argmax_rows(const void* x, int64_t* out, int64_t rows, int n,
     hipLaunchKernelGGL(argmax_rows_kernel<float>, dim3(cdiv(rows, 64)), dim3(64), 0, st, (const float*)x, out, (long)rows, n, (long)ld);
   else if (dtype == MSC_BF16)
     hipLaunchKernelGGL(argmax_rows_kernel<bf16_t>, dim3(cdiv(rows, 64)), dim3(64), 0, st, (const bf16_t*)x, out, (long)rows, n, (long)ld);
+  else
+    return MSC_ERR_BAD_ARG;
+  return msc_launch_status();
+}
+
+extern "C" int msc_topk_rows(const void* x, int64_t* out_idx, float* out_val, int64_t rows, int n, int k, int64_t ld, int dtype,
+                             void* stream) {
+  MSC_CHECK_ARG(x && out_idx && rows > 0 && n > 0 && n <= TOPK_MAX_N && k > 0 && k <= TOPK_MAX_K && k <= n && ld >= n);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSC_F32)
+    hipLaunchKernelGGL(topk_rows_kernel<float>, dim3(cdiv(rows, 64)), dim3(64), 0, st, (const float*)x, out_idx, out_val, (long)rows, n, k, (long)ld);
+  else if (dtype == MSC_BF16)
+    hipLaunchKernelGGL(topk_rows_kernel<bf16_t>, dim3(cdiv(rows, 64)), dim3(64), 0, st, (const bf16_t*)x, out_idx, out_val, (long)rows, n, k, (long)ld);
   else
     return MSC_ERR_BAD_ARG;
   return msc_launch_status();

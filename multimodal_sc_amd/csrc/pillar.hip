@@ -14,6 +14,7 @@
 // Traffic per 64-frame step: 0.35 GB (was 1.37 GB with the fp32 scatter grid: memset 268 + atomics 300 + cast 403 + backward 401).
 // HBM-bound gather.  Build-authored; the upstream reference has no code.
 #include "msc_common.h"
+#include <atomic>
 
 #define PIL_C 64
 #define PIL_BLOCKS 2048
@@ -292,13 +293,17 @@ extern "C" int msc_pillar_fwd(const float* points, const float* w, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int ncell = G * G;
   // up to 16 points per thread stay in registers (Np <= 16384); larger frames take the loop version
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: keyed on the current device (a bitmask under an atomic, so concurrent first calls from two host
+  // threads at worst both set it — the call is idempotent)
+  static std::atomic<uint64_t> attr_set{0};
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid > 63) return MSC_ERR_LAUNCH;
+  if (!((attr_set.load(std::memory_order_acquire) >> devid) & 1ull)) {
     if (hipFuncSetAttribute((const void*)pillar_sort_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (PIL_MAX_CELLS + PIL_MAX_CELLS / 16 + 1) * 4) != hipSuccess ||
         hipFuncSetAttribute((const void*)pillar_sort_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (PIL_MAX_CELLS + PIL_MAX_CELLS / 16 + 1) * 4) != hipSuccess ||
         hipFuncSetAttribute((const void*)pillar_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (PIL_MAX_CELLS + PIL_MAX_CELLS / 16 + 1) * 4) != hipSuccess)
       return MSC_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.fetch_or(1ull << devid, std::memory_order_release);
   }
   float4* sp = reinterpret_cast<float4*>(sorted_pts);
   if (Np <= 4 * 1024)

@@ -229,11 +229,12 @@ def linear_fwd(rt: Runtime, x2d, w: ParamRef, b: ParamRef, act=L.ACT_NONE, res=N
 
 
 def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_dx=True, bias_done=False,
-               prev_act=L.ACT_NONE, prev_ref=None, prev_bias: ParamRef = None):
+               prev_act=L.ACT_NONE, prev_ref=None, prev_bias: ParamRef = None, res=None):
     """dy2d: gradient w.r.t. the layer output (after activation). ref: y (relu/tanh/sigmoid) or pre (gelu).
     prev_act/prev_ref/prev_bias: fuse the backward of the activation that FED this layer (and the bias gradient of the
     layer that produced it) into the dgrad epilogue — the returned dx is then the gradient w.r.t. that pre-activation
-    and prev_bias.g is filled; the caller passes act=ACT_NONE, bias_done=True to the previous layer's linear_bwd."""
+    and prev_bias.g is filled; the caller passes act=ACT_NONE, bias_done=True to the previous layer's linear_bwd.
+    res: a gradient w.r.t. the layer INPUT arriving over another branch, added inside the dgrad epilogue (before prev_act')."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     if act != L.ACT_NONE:
@@ -262,7 +263,7 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
         if prev_bias is not None:
             nblk = L.query("msc_linear_dgrad_colsum_rows", M, K, rt.dt)
             part = rt.workspace("dgrad_colsum", nblk * K * 4)
-        rt.call("msc_linear_dgrad", d, w.t, prev_ref, prev_act, part, dx, M, N, K, rt.dt)
+        rt.call("msc_linear_dgrad", d, w.t, res, prev_ref, prev_act, part, dx, M, N, K, rt.dt)
         if prev_bias is not None:
             rt.call("msc_colsum_finalize", part, nblk, K, prev_bias.g, rt.accumulate)
     return dx
@@ -308,6 +309,42 @@ class MLP2(torch.autograd.Function):
         dh = linear_bwd(rt, dy2d, h, yref, w2, b2, act2, prev_act=act1, prev_ref=ref1 if act1 != L.ACT_NONE else None)
         dx = linear_bwd(rt, dh, x2d, None, w1, b1, L.ACT_NONE)
         return dx.view(shp), None, None, None, None, None, None, None
+
+
+class HeadsFn(torch.autograd.Function):
+    """Everything that reads the decoded feature z, as ONE autograd node with two outputs: the policy/value head
+    (fc + tanh -> packed [logits | value] rows) and the reconstruction head (fc1 + ReLU -> per-cell fc2 + sigmoid).  z has two
+    consumers; as separate nodes autograd would sum their two gradients with an add kernel of its own.  Here the head branch's
+    gradient rides into the reconstruction branch's dgrad epilogue as `res` (one fp32 sum, one rounding, no extra launch), and the
+    two activation backwards in front of the second layers ride in those layers' dgrad epilogues (prev_act)."""
+
+    @staticmethod
+    def forward(ctx, z, rt, hw1, hb1, hw2, hb2, rw1, rb1, rw2, rb2, cells, recon_hidden):
+        z2d = z.reshape(-1, z.shape[-1])
+        B = z2d.shape[0]
+        h, _ = linear_fwd(rt, z2d, hw1, hb1, L.ACT_TANH)
+        head, _ = linear_fwd(rt, h, hw2, hb2, L.ACT_NONE)
+        r1, _ = linear_fwd(rt, z2d, rw1, rb1, L.ACT_RELU)
+        r1v = r1.view(B * cells, recon_hidden)
+        patches, _ = linear_fwd(rt, r1v, rw2, rb2, L.ACT_SIGMOID)
+        ctx.save_for_backward(z2d, h, r1v, patches)
+        ctx.cfg = (rt, hw1, hb1, hw2, hb2, rw1, rb1, rw2, rb2, z.shape)
+        ctx.set_materialize_grads(False)
+        return head, patches
+
+    @staticmethod
+    def backward(ctx, dhead, dpat):
+        z2d, h, r1v, patches = ctx.saved_tensors
+        rt, hw1, hb1, hw2, hb2, rw1, rb1, rw2, rb2, shp = ctx.cfg
+        B = z2d.shape[0]
+        dz = None
+        if dhead is not None:
+            dh = linear_bwd(rt, dhead.contiguous(), h, None, hw2, hb2, L.ACT_NONE, prev_act=L.ACT_TANH, prev_ref=h)
+            dz = linear_bwd(rt, dh, z2d, None, hw1, hb1, L.ACT_NONE, need_dx=True)
+        if dpat is not None:
+            dr1 = linear_bwd(rt, dpat.contiguous(), r1v, patches, rw2, rb2, L.ACT_SIGMOID, prev_act=L.ACT_RELU, prev_ref=r1v)
+            dz = linear_bwd(rt, dr1.view(B, -1), z2d, None, rw1, rb1, L.ACT_NONE, res=dz)
+        return (dz.view(shp) if dz is not None else None,) + (None,) * 11
 
 
 class LinearFP8(torch.autograd.Function):
@@ -476,7 +513,11 @@ def _fusion_fwd_two_chains(ctx, x, rt, p, h):
     Tpad = L.query("msc_attention_tpad", T)
     lse = rt.f32(B * h, Tpad)
     scale = 1.0 / math.sqrt(hd)
-    if p.get("first", True):                                      # the tokens were assembled on the main stream
+    saving = bool(ctx.needs_input_grad[0])      # (torch.is_grad_enabled() is always False inside Function.forward)
+    if p.get("first", True) or not saving:
+        # first layer: the tokens were assembled on the main stream.  Inference / rollout (nothing saved): EVERY layer orders chain B
+        # behind the main stream, because this layer's buffers come from the caching allocator and may be blocks the main stream
+        # freed a layer ago — chain B must not write them while chain A of the previous layer still reads them
         L.call("msc_stream_wait_stream", s2, main, ev_ab)
     # Raw device addresses of the chains' row ranges (plain integer arithmetic: slicing ~60 tensor views per layer costs the host
     # more than the launches themselves, and the host paces the launch-dense fusion backward)
@@ -508,7 +549,7 @@ def _fusion_fwd_two_chains(ctx, x, rt, p, h):
         call("msc_linear_fwd", a_u + r0 * rF, w2, b2, a_x1 + r0 * rD, a_x2 + r0 * rD, None, n, D, Fh, L.ACT_NONE, dt, c)
     if p.get("last", True):                                       # the final LayerNorm reads the whole batch on the main stream
         L.call("msc_stream_wait_stream", main, s2, ev_ba)
-    if not (torch.is_grad_enabled() and x.requires_grad):
+    if not saving:
         # inference / rollout collection: nothing keeps these buffers alive for a backward, and the caching allocator would hand
         # them back to the main stream while the second chain still uses them
         s2t = rt.branch_stream()
@@ -517,6 +558,7 @@ def _fusion_fwd_two_chains(ctx, x, rt, p, h):
     ctx.save_for_backward(x2d, st, h1, qkv, lse, o, x1, h2, upre, u)
     ctx.cfg = (rt, p, h, (B, T, D))
     ctx.two = True
+    ctx.side_was_active = rt.side_active()      # the backward's weight gradients must take the same route (asserted there)
     return x2.view(B, T, D)
 
 
@@ -524,6 +566,10 @@ def _fusion_bwd_two_chains(ctx, dy):
     rt, p, h, (B, T, D) = ctx.cfg
     hd, M, Fh = D // h, B * T, p["fc1w"].shape[0]
     x2d, st, h1, qkv, lse, o, x1, h2, upre, u = ctx.saved_tensors
+    if not (rt.side_active() and ctx.side_was_active):
+        # call_side() would fall back to the launching stream and run the whole-batch weight gradient without waiting for chain B
+        raise RuntimeError("the two-chain fusion backward needs the side stream it was recorded with (rt.profile / MSC_SIDE_STREAM "
+                           "changed between forward and backward)")
     main = rt.stream
     s2, ev_ab, ev_ba, ev_bs = rt.chain_b()
     dx2 = dy.reshape(M, D).contiguous()
@@ -569,23 +615,23 @@ def _fusion_bwd_two_chains(ctx, dy):
         wgrad(u, dx2, p["fc2w"], p["fc2b"])
         # fc2's dgrad epilogue applies GELU' (from the saved pre-activation)
         for c, r0, n, _, _, _ in chains:
-            call("msc_linear_dgrad", a_dx2 + r0 * rD, t2, a_upre + r0 * rF, L.ACT_GELU, None, a_dpre + r0 * rF, n, D, Fh, dt, c)
+            call("msc_linear_dgrad", a_dx2 + r0 * rD, t2, None, a_upre + r0 * rF, L.ACT_GELU, None, a_dpre + r0 * rF, n, D, Fh, dt, c)
         wgrad(h2, dpre, p["fc1w"], p["fc1b"])
         for c, r0, n, _, _, _ in chains:
-            call("msc_linear_dgrad", a_dpre + r0 * rF, t1, None, L.ACT_NONE, None, a_dh2 + r0 * rD, n, Fh, D, dt, c)
+            call("msc_linear_dgrad", a_dpre + r0 * rF, t1, None, None, L.ACT_NONE, None, a_dh2 + r0 * rD, n, Fh, D, dt, c)
         for c, r0, n, _, _, ci in chains:
             call("msc_layernorm_bwd", a_dh2 + r0 * rD, a_x1 + r0 * rD, a_st + (2 * M + r0) * 4, a_st + (3 * M + r0) * 4, ln2g, a_dx2 + r0 * rD,
                  a_dx1 + r0 * rD, lnt_ptr(ci, 1, 0), lnt_ptr(ci, 1, 1), lnws[ci], n, D, 0, dt, c)
         wgrad(o, dx1, p["projw"], p["projb"])
         ln_sum(1, p["ln2g"], p["ln2b"])
         for c, r0, n, _, _, _ in chains:
-            call("msc_linear_dgrad", a_dx1 + r0 * rD, tp, None, L.ACT_NONE, None, a_do + r0 * rD, n, D, D, dt, c)
+            call("msc_linear_dgrad", a_dx1 + r0 * rD, tp, None, None, L.ACT_NONE, None, a_do + r0 * rD, n, D, D, dt, c)
         for c, r0, n, l0, nb, _ in chains:
             call("msc_attention_bwd", a_qkv + r0 * r3D, a_o + r0 * rD, a_do + r0 * rD, a_lse + l0 * Tpad * 4, a_delta + l0 * Tpad * 4,
                  a_dqkv + r0 * r3D, nb, T, h, hd, scale, dt, c)
         wgrad(h1, dqkv, p["qkvw"], p["qkvb"])
         for c, r0, n, _, _, _ in chains:
-            call("msc_linear_dgrad", a_dqkv + r0 * r3D, tq, None, L.ACT_NONE, None, a_dh1 + r0 * rD, n, 3 * D, D, dt, c)
+            call("msc_linear_dgrad", a_dqkv + r0 * r3D, tq, None, None, L.ACT_NONE, None, a_dh1 + r0 * rD, n, 3 * D, D, dt, c)
         for c, r0, n, _, _, ci in chains:
             call("msc_layernorm_bwd", a_dh1 + r0 * rD, a_x + r0 * rD, a_st + r0 * 4, a_st + (M + r0) * 4, ln1g, a_dx1 + r0 * rD, a_dx + r0 * rD,
                  lnt_ptr(ci, 0, 0), lnt_ptr(ci, 0, 1), lnws[ci], n, D, 0, dt, c)

@@ -4,7 +4,8 @@ The upstream reference ships no code (SURVEY.md finding zero), so the "reference
 module/state_dict naming of the build-authored oracle (oracle/model.py): same keys, same forward signature
 `model(image, points, state, snr_db, noise, fading)`.  Conv weights are held OHWI (channels-last) and the
 policy/value output layers are packed into one [16,hidden] matrix; load_oracle_state_dict/export_state_dict
-convert.  Nothing in this file runs math on the CPU or through torch ops: every layer is a C-ABI kernel call.
+convert.  Nothing in this file runs math on the CPU or through torch ops: every layer is a C-ABI kernel call (tensors with two
+consumers are handled inside one autograd node, so autograd never launches an add of its own: functional.HeadsFn).
 """
 from __future__ import annotations
 
@@ -344,10 +345,12 @@ class MultimodalSC:
             if inkernel:
                 rt.call("msc_counter_add", self.draw_dev, 1)
         z = self._mlp2(rx, "semantic_decoder.fc1", L.ACT_RELU, "semantic_decoder.fc2", L.ACT_NONE)
-        head = self._mlp2(z, "head.fc", L.ACT_TANH, "head.out", L.ACT_NONE)
-        g = cfg.recon_grid
-        r1 = self._lin(z, "recon.fc1", L.ACT_RELU).view(B * g * g, cfg.recon_hidden)
-        patches = self._lin(r1, "recon.fc2", L.ACT_SIGMOID)
+        # policy/value head + reconstruction head: one autograd node (z has two consumers; functional.HeadsFn sums their
+        # gradients inside a dgrad epilogue instead of an add kernel)
+        g, P = cfg.recon_grid, self.params
+        head, patches = F.HeadsFn.apply(z, rt, P["head.fc.weight"], P["head.fc.bias"], P["head.out.weight"], P["head.out.bias"],
+                                        P["recon.fc1.weight"], P["recon.fc1.bias"], P["recon.fc2.weight"], P["recon.fc2.bias"],
+                                        g * g, cfg.recon_hidden)
         return {"head": head, "patches": patches, "symbols": sym, "rx": rx, "feature": f, "z": z}
 
     __call__ = forward
@@ -365,6 +368,16 @@ class MultimodalSC:
         act = torch.empty(B, dtype=torch.int64, device=rt.device)
         rt.call("msc_argmax_rows", out["head"], act, B, self.cfg.n_actions, HEAD_PAD, rt.dt)
         return act
+
+    def select_topk(self, out, k: int):
+        """the k best actions per frame, order (logit descending, index ascending on exact ties): int64 [B,k] (bit-exact integer
+        output) and their logits fp32 [B,k]; k = 1 is select_action."""
+        rt = self.rt
+        B = out["head"].shape[0]
+        idx = torch.empty(B, k, dtype=torch.int64, device=rt.device)
+        val = rt.f32(B, k)
+        rt.call("msc_topk_rows", out["head"], idx, val, B, self.cfg.n_actions, k, HEAD_PAD, rt.dt)
+        return idx, val
 
     def recon_image(self, out):
         rt, cfg = self.rt, self.cfg

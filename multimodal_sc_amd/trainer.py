@@ -116,14 +116,16 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if self.world > 1:
             model.channel_rank = dist.get_rank()      # every rank draws its own channel noise (Philox key word)
-            if getattr(model, "_img_cut_auto", False):
-                model._img_cut = 3                    # boundary inside the camera trunk: the exchange's mid piece starts there
         self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
         self.split = model.params.refs["fusion.pos_embed"].off
         self.use_graph = os.environ.get("MSC_HIP_GRAPH", "0") == "1"
         if self.use_graph:
             model.rt.host_counters = False     # a replayed launch sequence needs its step / noise-draw numbers on the device
         self.dp_pieces = int(os.environ.get("MSC_DP_PIECES", "3"))    # 2: upper + encoders; 3: upper + mid + rest of the trunk
+        if self.world > 1 and getattr(model, "_img_cut_auto", False) and self.overlap and self.dp_pieces >= 3 and not self.use_graph:
+            # boundary inside the camera trunk: the exchange's mid piece starts there.  Only the schedule that issues a mid piece
+            # pays for the boundary (one GPU: 8.12 -> 8.25 ms); two-piece, non-overlapped and hipGraph DP keep the uncut trunk
+            model._img_cut = 3
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
         self.exchange = None      # GradExchange, built on the first multi-rank step (needs the model's mid offset)
         self._seen = 0

@@ -425,6 +425,13 @@ def select_action(logits):
     return torch.argmax(logits, dim=-1)
 
 
+def select_topk(logits, k):
+    """the k best actions, order (logit descending, index ascending on exact ties) — oracle/rl.py topk_rows"""
+    from .rl import topk_rows
+    idx, val = topk_rows(logits.detach().numpy(), k)
+    return torch.from_numpy(idx), torch.from_numpy(val)
+
+
 def psnr(recon, image):
     mse = (recon - image).pow(2).flatten(1).mean(1)
     return 10.0 * torch.log10(1.0 / mse)

@@ -58,3 +58,16 @@ def sample_actions(logits, seed, step, return_margin=False):
     if return_margin:
         return pick, logp.astype(f32), margin
     return pick, logp.astype(f32)
+
+
+def topk_rows(x, k):
+    """x [rows, n] -> (idx int64 [rows,k], val float32 [rows,k]).  Order: value descending, index ascending on exact ties
+    (0.0 and -0.0 tie), NaN after everything else (also after -inf) — a stable lexicographic sort on (isnan, -value, index);
+    k = 1 is arg-max with the lowest index on ties (oracle.model.select_action on finite logits)."""
+    x = np.asarray(x, dtype=f32)
+    rows, n = x.shape
+    nan = np.isnan(x)
+    negv = np.where(nan, f32(0), -x) + f32(0)            # + 0 turns -0.0 into 0.0 so the two zeros compare equal as keys
+    j = np.broadcast_to(np.arange(n), x.shape)
+    order = np.lexsort((j, negv, nan), axis=-1)[:, :k]   # last key is the primary one
+    return order.astype(np.int64), np.take_along_axis(x, order, axis=1)

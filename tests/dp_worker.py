@@ -1,5 +1,6 @@
 """Child process of tests/test_dp_gpu.py: one data-parallel rank running Trainer.step on cuda:0.
-usage: python dp_worker.py <rank> <world> <port> <out.pt> <config> <frames> <steps>
+usage: python dp_worker.py <rank> <world> <port> <out.pt> <config> <frames> <steps> [shard]
+world == 1: a single-process run (no process group) of shard `shard` — the independent answer the DP runs are checked against.
 Ranks share the one GPU of the test box and exchange gradients through gloo (host memory) — the same Trainer code path
 the real runs take over RCCL, one rank per GPU.  Schedule knobs (MSC_DP_PIECES, MSC_DP_OVERLAP) come from the environment."""
 import os
@@ -11,6 +12,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, out, cfg_name, B, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
+    shard = int(sys.argv[8]) if len(sys.argv) > 8 else rank
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     import torch
@@ -19,11 +21,13 @@ def main():
     from multimodal_sc_amd.synthetic import synthetic_batch
     from multimodal_sc_amd.trainer import Trainer
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = named_config(cfg_name)
     m = MultimodalSC(cfg, dtype="bf16", device="cuda:0", seed=0)          # same seed: identical initial parameters
     tr = Trainer(m, lr=1e-3)
-    cb = synthetic_batch(cfg, B, seed=100 + rank)                           # each rank its own shard of frames
+    m.channel_rank = shard
+    cb = synthetic_batch(cfg, B, seed=100 + shard)                          # each rank its own shard of frames
     gb = {k: (v.to("cuda:0") if torch.is_tensor(v) else v) for k, v in cb.items() if k != "ppo"}
     gb["ppo"] = {k: v.to("cuda:0") for k, v in cb["ppo"].items()}
     for _ in range(steps):
@@ -33,8 +37,9 @@ def main():
     torch.cuda.synchronize()
     log = list(tr.exchange.log) if tr.exchange is not None else []
     torch.save({"P": m.params.P.cpu(), "G": m.params.G.cpu(), "log": log}, out)
-    dist.barrier()
-    dist.destroy_process_group()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -43,7 +43,29 @@ def model_case(name, B, seed_model=1, seed_batch=2):
     return rec
 
 
+def topk_case():
+    """top-k action selection (north_star: 'bit-exact for index/top-k action selection'): hand-built rows with exact ties, signed
+    zeros, infinities and NaN, plus random rows on the bf16 grid (so the same vectors serve both storage types)."""
+    rng = np.random.default_rng(11)
+    hand = np.array([[1, 3, 3, 2, 3, 0, 0, 0, 0], [5, 5, 5, 5, 5, 5, 5, 5, 5], [-1, -2, -1, -3, -1, -2, -9, -9, -9],
+                     [0.0, -0.0, 0.0, -0.0, 1, 1, -1, -1, 0.0], [np.inf, 1, -np.inf, np.inf, 2, 2, -np.inf, 0, 0],
+                     [np.nan, 1, np.nan, 1, 0, -np.inf, np.nan, 2, 2], [np.nan] * 9], np.float32)
+    rand = torch.from_numpy(rng.normal(size=(200, 9)).astype(np.float32)).to(torch.bfloat16).float().numpy()
+    coarse = np.round(rng.normal(size=(200, 9)) * 2).astype(np.float32) / 2        # many exact ties
+    x = np.concatenate([hand, rand, coarse], 0)
+    rec = {"x": x}
+    for k in (1, 3, 8):
+        idx, val = rl.topk_rows(x, k)
+        rec[f"idx{k}"], rec[f"val{k}"] = idx, val
+    return rec
+
+
 def main():
+    if "--only-new" in sys.argv:       # adds the fixtures of later rounds without touching the frozen earlier files
+        np.savez_compressed(os.path.join(HERE, "topk.npz"), **topk_case())
+        print("wrote topk.npz")
+        return
+    np.savez_compressed(os.path.join(HERE, "topk.npz"), **topk_case())
     np.savez_compressed(os.path.join(HERE, "oracle_c0_b8.npz"), **model_case("C0", 8))
     r = philox.philox4x32_10(np.array([0, 1, 0xFFFFFFFF], np.uint32), np.array([0, 2, 0xFFFFFFFF], np.uint32),
                              np.array([0, 3, 0xFFFFFFFF], np.uint32), np.array([0, 4, 0xFFFFFFFF], np.uint32), 0x0, 0x0)

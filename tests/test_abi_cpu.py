@@ -40,6 +40,13 @@ def test_library_exports_nothing_undeclared(built_lib):
     assert exported == set(L.parse_header().keys())
 
 
+def test_build_id_matches_checked_out_sources(built_lib):
+    """the loaded .so was built from THESE sources: msc_build_id() == the hash csrc/Makefile embeds, recomputed here"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _buildid import source_build_id
+    assert built_lib.lib.msc_build_id().decode() == source_build_id()
+
+
 def test_pure_host_entry_points(built_lib):
     L = built_lib
     assert L.lib.msc_version() >= 100

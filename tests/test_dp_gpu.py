@@ -26,13 +26,13 @@ def _free_port():
     return port
 
 
-def _run_world(tmp_path, tag, env_extra, cfg="C3", frames=2, steps=3, world=2):
+def _run_world(tmp_path, tag, env_extra, cfg="C3", frames=2, steps=3, world=2, shard=None):
     port = str(_free_port())
     env = dict(os.environ, **env_extra)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     outs = [str(tmp_path / f"{tag}_r{r}.pt") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, outs[r], cfg,
-                               str(frames), str(steps)], env=env) for r in range(world)]
+                               str(frames), str(steps)] + ([str(shard)] if shard is not None else []), env=env) for r in range(world)]
     rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0] * world, (tag, rcs)
     return [torch.load(o, weights_only=True) for o in outs]
@@ -53,3 +53,27 @@ def test_overlapped_dp_step_matches_other_schedules(cuda, tmp_path, cfg):
     for tag in ("p2", "flat"):
         assert torch.equal(runs["p3"][0]["G"], runs[tag][0]["G"]), f"3-piece vs {tag}: reduced gradients differ"
         assert torch.equal(runs["p3"][0]["P"], runs[tag][0]["P"]), f"3-piece vs {tag}: parameters differ"
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C1"])
+def test_dp_sum_equals_independent_single_rank_gradients(cuda, tmp_path, cfg):
+    """The independent answer (SURVEY.md §4 'N-rank result equals single-rank result').  BatchNorm statistics are per GPU, so a
+    rank's gradient does not depend on the other rank: after ONE step at world 2 the reduced gradient must equal
+    G(shard 0 alone) + G(shard 1 alone) bit for bit (a + b is exact-rounded in any order), and the parameters must equal a
+    single-process fused-Adam update with that summed gradient scaled by 1/2.  A defect common to every DP schedule (a piece
+    reduced before it is final, grad_scale applied wrongly) passes the schedule-vs-schedule test above and fails here."""
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    dp = _run_world(tmp_path, "dp", {"MSC_DP_PIECES": "3", "MSC_DP_OVERLAP": "1"}, cfg, steps=1)
+    alone = [_run_world(tmp_path, f"alone{s}", {}, cfg, steps=1, world=1, shard=s)[0] for s in (0, 1)]
+    want_G = alone[0]["G"] + alone[1]["G"]
+    assert want_G.abs().max() > 0
+    assert torch.equal(dp[0]["G"], want_G), "reduced gradient != sum of the two ranks' stand-alone gradients"
+    assert torch.equal(dp[1]["G"], want_G)
+    # the single-process optimizer step on the summed gradient, grad_scale = 1 / world
+    m = MultimodalSC(named_config(cfg), dtype="bf16", device="cuda:0", seed=0)
+    m.params.G.copy_(want_G.to("cuda:0"))
+    m.params.adam_step(lr=1e-3, grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(dp[0]["P"], m.params.P.cpu()), "parameters != Adam(sum of gradients / 2)"
+    # and a lone rank's own update differs from it (the check is not vacuous)
+    assert not torch.equal(alone[0]["P"], dp[0]["P"])

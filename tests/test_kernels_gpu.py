@@ -136,7 +136,7 @@ def test_linear_dgrad_fused_act_and_bias(rts, dtype, M, N, K, act):
     dx = rt.empty(M, K)
     nblk = L.query("msc_linear_dgrad_colsum_rows", M, K, rt.dt)
     part = torch.full((nblk, K), float("nan"), device=rt.device)
-    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, dev(ref_in.detach(), rt), act, part, dx, M, N, K, rt.dt)
+    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, None, dev(ref_in.detach(), rt), act, part, dx, M, N, K, rt.dt)
     check("dx", dx, pq.grad, tol(dtype) * 2)
     db = torch.empty(K, device=rt.device)
     rt.call("msc_colsum_finalize", part, nblk, K, db, 0)
@@ -225,13 +225,13 @@ def test_persistent_linear_dgrad_fused(rts, monkeypatch, tile):
     (TF.gelu(pq) @ q(w, "bf16").t()).backward(q(dy, "bf16"))
     Wp = FakeParam(rt, w, "linear")
     dx = torch.full((M, K), float("nan"), device=rt.device, dtype=rt.tdtype)
-    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, dev(pre, rt), 2, None, dx, M, N, K, rt.dt)
+    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, None, dev(pre, rt), 2, None, dx, M, N, K, rt.dt)
     check("dx", dx, pq.grad, tol("bf16") * 2)
     nblk = L.query("msc_linear_dgrad_colsum_rows", M, K, rt.dt)
     assert nblk == (M + 127) // 128
     part = torch.full((nblk, K), float("nan"), device=rt.device)
     dx2 = torch.empty_like(dx)
-    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, dev(pre, rt), 2, part, dx2, M, N, K, rt.dt)
+    rt.call("msc_linear_dgrad", dev(dy, rt), Wp.t, None, dev(pre, rt), 2, part, dx2, M, N, K, rt.dt)
     check("dx2", dx2, pq.grad, tol("bf16") * 2)
     db = torch.empty(K, device=rt.device)
     rt.call("msc_colsum_finalize", part, nblk, K, db, 0)
@@ -691,6 +691,42 @@ def test_argmax_ties_bit_exact(rts):
         rt.call("msc_argmax_rows", dev(allx, rt), out, allx.shape[0], 4, 16, rt.dt)
         assert torch.equal(out.cpu(), torch.argmax(allx[:, :4], -1))
         assert out[:4].tolist() == [1, 0, 0, 2]
+
+
+def test_topk_rows_bit_exact(rts):
+    """msc_topk_rows against oracle/rl.py topk_rows and the committed fixture (hand-built exact ties, signed zeros, +-inf, NaN,
+    random rows on the bf16 grid): int64 indices AND values bit-exact for k = 1, 3, 8 in both storage types; k = 1 equals
+    msc_argmax_rows; padded columns (n < ld) are ignored."""
+    import os
+    import numpy as np
+    from oracle import rl as R
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "topk.npz"), allow_pickle=False)
+    x = torch.from_numpy(G["x"])
+    rows, n = x.shape
+    xp = torch.nn.functional.pad(x, (0, 16 - n), value=99.0)
+    for dtype in DTYPES:
+        rt = rts[dtype]
+        xd = dev(xp, rt)
+        for k in (1, 3, 8):
+            idx = torch.full((rows, k), -7, dtype=torch.int64, device=rt.device)
+            val = torch.full((rows, k), -7.0, device=rt.device)
+            rt.call("msc_topk_rows", xd, idx, val, rows, n, k, 16, rt.dt)
+            torch.cuda.synchronize()
+            assert np.array_equal(idx.cpu().numpy(), G[f"idx{k}"]), (dtype, k)
+            assert np.array_equal(val.cpu().numpy(), G[f"val{k}"], equal_nan=True), (dtype, k)
+            oi, ov = R.topk_rows(G["x"], k)
+            assert np.array_equal(idx.cpu().numpy(), oi)
+        am = torch.empty(rows, dtype=torch.int64, device=rt.device)
+        rt.call("msc_argmax_rows", xd, am, rows, n, 16, rt.dt)
+        i1 = torch.empty(rows, 1, dtype=torch.int64, device=rt.device)
+        rt.call("msc_topk_rows", xd, i1, None, rows, n, 1, 16, rt.dt)           # out_val is optional
+        torch.cuda.synchronize()
+        assert torch.equal(am, i1[:, 0])
+    # argument validation: k > 8, k > n, n > 32 are refused
+    rt = rts["f32"]
+    from multimodal_sc_amd import lib as L
+    for bad in ((9, 9), (4, 5), (40, 2)):
+        assert L.lib.msc_topk_rows(1, 1, None, 4, bad[0], bad[1], 64, 0, None) == -1
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -127,3 +127,25 @@ def test_golden_oracle_c0():
     g = {k: p.grad for k, p in om.named_parameters()}
     norms = np.array([float(g[k].double().norm()) for k in G["grad_names"]])
     assert np.allclose(norms, G["grad_norm"], rtol=2e-2, atol=1e-7)     # training-mode BN over 8 samples: ill-conditioned
+
+
+def test_topk_rows_known_answers_and_golden():
+    """top-k order = (value desc, index asc), NaN last: against a plain Python sort with that key, hand cases, and the committed
+    fixture tests/golden/topk.npz (which the HIP kernel is held to bit-exactly in tests/test_kernels_gpu.py)."""
+    import os
+    from oracle import rl as R
+    from oracle.model import select_action
+    x = np.array([[1, 3, 3, 2], [5, 5, 5, 5], [0.0, -0.0, 1, 1], [np.nan, 2, np.nan, -np.inf]], np.float32)
+    idx, val = R.topk_rows(x, 4)
+    assert idx.tolist() == [[1, 2, 3, 0], [0, 1, 2, 3], [2, 3, 0, 1], [1, 3, 0, 2]]
+    assert val[0].tolist() == [3, 3, 2, 1] and np.isnan(val[3, 2:]).all()
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "topk.npz"), allow_pickle=False)
+    xs = G["x"]
+    for k in (1, 3, 8):
+        idx, val = R.topk_rows(xs, k)
+        assert np.array_equal(idx, G[f"idx{k}"]) and np.array_equal(val, G[f"val{k}"], equal_nan=True)
+        for r in range(xs.shape[0]):        # independent restatement: Python's stable sort on the same key
+            key = lambda j: (bool(np.isnan(xs[r, j])), 0.0 if np.isnan(xs[r, j]) else -float(xs[r, j]), j)
+            assert idx[r].tolist() == sorted(range(xs.shape[1]), key=key)[:k], r
+    finite = np.isfinite(xs).all(1)
+    assert np.array_equal(R.topk_rows(xs, 1)[0][finite, 0], select_action(torch.from_numpy(xs[finite])).numpy())

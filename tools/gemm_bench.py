@@ -38,7 +38,7 @@ for name, N, K, act, res, pre in [("qkv", 1536, 512, 0, 0, 0), ("proj+res", 512,
     t = timeit(lambda: rt.call("msc_linear_fwd", x, w, b, r if res else None, y, p if pre else None, M, N, K, act, rt.dt))
     rows.append((f"linear_fwd {name} M{M} N{N} K{K}", t, fl))
     dy, wt, dx = rnd(M, N), rnd(K, N), rnd(M, K)
-    t = timeit(lambda: rt.call("msc_linear_dgrad", dy, wt, None, 0, None, dx, M, N, K, rt.dt))
+    t = timeit(lambda: rt.call("msc_linear_dgrad", dy, wt, None, None, 0, None, dx, M, N, K, rt.dt))
     rows.append((f"linear_dgrad {name}", t, fl))
     dw = torch.empty(N, K, device=dev)
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M)

@@ -40,7 +40,7 @@ for name, N, K in [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), (
                   rt.call("msc_linear_fwd", x, w, b, r if res else None, y, p if pre else None, M, N, K, act, rt.dt)), ALL))
     dy, wt, dx = rnd(M, N), rnd(K, N), rnd(M, K)
     cases.append((f"lin_dgrad {name} out{K} red{N}", fl, (lambda dy=dy, wt=wt, dx=dx, N=N, K=K:
-                  rt.call("msc_linear_dgrad", dy, wt, None, 0, None, dx, M, N, K, rt.dt)), ALL))
+                  rt.call("msc_linear_dgrad", dy, wt, None, None, 0, None, dx, M, N, K, rt.dt)), ALL))
     dw = torch.empty(N, K, device=dev)
     wsb = L.query("msc_wgrad_workspace_bytes", N, K, M) * 4
     ws = torch.empty(wsb // 4, device=dev)
