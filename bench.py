@@ -114,7 +114,7 @@ def gemm_bytes(name, s):
     return None
 
 
-def cpu_baseline(cfg_name, seconds_budget=60.0):
+def cpu_baseline(cfg_name, seconds_budget=80.0):
     """oracle fwd+bwd (fp32, all host threads) on a bounded sample of the same workload -> frames/s.
     Procedure (BASELINE.md "CPU-baseline plan"): 2 warm-up steps + 5 timed steps at one batch size, MEDIAN step time.
     The batch is 32 frames when one probing step at 16 frames says 7 steps of 32 fit the time budget, else 16 (a small

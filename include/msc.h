@@ -268,6 +268,24 @@ int msc_sample_actions(const void* head, int64_t* action, float* logp, float* va
 int msc_symbols_pack(const void* x, void* q, float* scale, int B, int k, int dtype, void* stream);
 int msc_symbols_unpack(const void* q, const float* scale, void* y, int B, int k, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Launch replay (host side of the training step; csrc/replay.hip, multimodal_sc_amd/replay.py).  A program is the recorded list
+ * of int-returning entry-point calls of one eager step (function id + argument values, stream handles and event waits
+ * included), cut into segments where the host must act between launches (the DP all-reduces).  msc_replay_run re-issues a
+ * segment through the same entry points: one call from the host per segment instead of one per launch.  The caller keeps every
+ * recorded buffer alive and unchanged in address (per-step bump arena); step / noise-draw numbers must be device-side counters.
+ * iargs[j] carries integer and pointer arguments (as int64), fargs[j] float arguments (as double). */
+#define MSC_REPLAY_MAX_ARGS 24
+int msc_replay_fn_id(const char* name);              /* -1 when `name` is not a replayable entry point */
+int msc_replay_fn_nargs(int fn_id);
+int64_t msc_replay_create(void);
+int msc_replay_destroy(int64_t prog);
+int msc_replay_add(int64_t prog, int fn_id, const int64_t* iargs, const double* fargs, int nargs);
+int msc_replay_cut(int64_t prog);                    /* closes the current segment; returns the index of the next one */
+int64_t msc_replay_count(int64_t prog, int segment); /* records in a segment (all when segment < 0) */
+int msc_replay_run(int64_t prog, int segment);       /* segment < 0: every segment */
+int64_t msc_replay_last_failed(int64_t prog);
+
 #ifdef __cplusplus
 }
 #endif

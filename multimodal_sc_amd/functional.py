@@ -60,8 +60,8 @@ def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: Para
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = conv.shape
     M = y_raw.numel() // Cout
-    d_raw = torch.empty_like(y_raw)
-    dres = torch.empty_like(y_raw) if want_dres else None
+    d_raw = rt.empty_like(y_raw)
+    dres = rt.empty_like(y_raw) if want_dres else None
     ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
     xmask = relu and not had_res and _MASK_FROM_X
     rt.call("msc_bn_bwd", dy, y_raw, y, stats[0], stats[1], gamma.p, stats[2] if xmask else None, stats[3] if xmask else None,
@@ -81,7 +81,7 @@ def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: Para
     wgrad()
     dx = None
     if need_dx:
-        dx = torch.empty_like(x)
+        dx = rt.empty_like(x)
         wsd = L.query("msc_conv2d_splitk_workspace_bytes", B * H * W, Cin, KH * KW * Cout, rt.dt) if stride == 1 else 0
         ws = rt.workspace("conv_splitk", wsd) if wsd else None
         rt.call("msc_conv2d_dgrad", d_raw, conv.t, dx_res, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsd, rt.dt)
@@ -127,7 +127,7 @@ class StemFn(torch.autograd.Function):
         rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, gamma.p, beta.p, stats[0], stats[1], stats[2], stats[3])
         Hp, Wp = (Ho + 2 * pP - pK) // pS + 1, (Wo + 2 * pP - pK) // pS + 1
         y = rt.empty(B, Hp, Wp, Cout)
-        idx = torch.empty(B, Hp, Wp, Cout, dtype=torch.uint8, device=x.device)
+        idx = rt.alloc((B, Hp, Wp, Cout), torch.uint8)
         xsel = rt.empty(B, Hp, Wp, Cout)      # conv output at each window's arg-max: the backward's statistics pass reads this, not y_raw
         rt.call("msc_bn_relu_pool_fwd", y_raw, stats[2], stats[3], y, idx, xsel, B, Ho, Wo, Cout, pK, pS, pP, rt.dt)
         if rt.taps is not None:   # parity tests compare ReLU masks: materialise the activation the fused pass never stores
@@ -145,7 +145,7 @@ class StemFn(torch.autograd.Function):
         B, H, W, Cin = x.shape
         Cout, KH, KW, _ = conv.shape
         _, Ho, Wo, _ = y_raw.shape
-        d_raw = torch.empty_like(y_raw)
+        d_raw = rt.empty_like(y_raw)
         ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
         rt.call("msc_bn_relu_pool_bwd", dy.contiguous(), idx, xsel, y_raw, stats[0], stats[1], gamma.p, stats[2], stats[3], d_raw, gamma.g, beta.g,
                 ws, B, Ho, Wo, Cout, pK, pS, pP, rt.accumulate, rt.dt)
@@ -202,7 +202,7 @@ class MaxPool(torch.autograd.Function):
         B, H, W, C = x.shape
         Ho, Wo = (H + 2 * P - K) // S + 1, (W + 2 * P - K) // S + 1
         y = rt.empty(B, Ho, Wo, C)
-        idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+        idx = rt.alloc((B, Ho, Wo, C), torch.uint8)
         rt.call("msc_maxpool_fwd", x, y, idx, B, H, W, C, K, S, P, rt.dt)
         ctx.save_for_backward(idx)
         ctx.cfg = (rt, x.shape, K, S, P)
@@ -238,7 +238,7 @@ def linear_bwd(rt: Runtime, dy2d, x2d, ref, w: ParamRef, b: ParamRef, act, need_
     M, N = dy2d.shape
     K = x2d.shape[1]
     if act != L.ACT_NONE:
-        d = torch.empty_like(dy2d)
+        d = rt.empty_like(dy2d)
         rt.call("msc_act_bwd", dy2d, ref, d, M * N, act, rt.dt)
     else:
         d = dy2d
@@ -359,8 +359,8 @@ class LinearFP8(torch.autograd.Function):
         M, K = x2d.shape
         N = w.shape[0]
         dev = rt.device
-        xq = torch.empty(M, K, dtype=torch.uint8, device=dev)
-        wq = torch.empty(N, K, dtype=torch.uint8, device=dev)
+        xq = rt.alloc((M, K), torch.uint8)
+        wq = rt.alloc((N, K), torch.uint8)
         xh, wh = rt.empty(M, K), rt.empty(N, K)
         sc = rt.f32(2)
         rt.call("msc_fp8_quantize", x2d, xq, xh, sc[0:1], M * K, rt.dt, rt.dt)
@@ -379,7 +379,7 @@ class LinearFP8(torch.autograd.Function):
         M, N = dy2d.shape
         K = xh.shape[1]
         if act != L.ACT_NONE:
-            d = torch.empty_like(dy2d)
+            d = rt.empty_like(dy2d)
             rt.call("msc_act_bwd", dy2d, ref, d, M * N, act, rt.dt)
         else:
             d = dy2d
@@ -396,7 +396,7 @@ class LinearFP8(torch.autograd.Function):
 
 def layernorm_fwd(rt, x2d, g: ParamRef, b: ParamRef):
     R, D = x2d.shape
-    y = torch.empty_like(x2d)
+    y = rt.empty_like(x2d)
     mean, rstd = rt.f32(R), rt.f32(R)
     rt.call("msc_layernorm_fwd", x2d, g.p, b.p, y, mean, rstd, R, D, LN_EPS, rt.dt)
     return y, mean, rstd
@@ -404,7 +404,7 @@ def layernorm_fwd(rt, x2d, g: ParamRef, b: ParamRef):
 
 def layernorm_bwd(rt, dy2d, x2d, mean, rstd, g: ParamRef, b: ParamRef, dadd=None):
     R, D = x2d.shape
-    dx = torch.empty_like(x2d)
+    dx = rt.empty_like(x2d)
     ws = rt.workspace("ln_bwd", L.query("msc_layernorm_bwd_workspace_bytes", R, D))
     rt.call("msc_layernorm_bwd", dy2d, x2d, mean, rstd, g.p, dadd, dx, g.g, b.g, ws, R, D, rt.accumulate, rt.dt)
     return dx
@@ -476,7 +476,7 @@ def attention_bwd(rt: Runtime, do, qkv, o, P, B, T, h, hd):
     # dP[q][key] = sum_d dO[q][d] V[key][d]
     dP = rt.workspace("attn_scores", nb * T * Tp * 4)
     rt.call("msc_gemm_batched", do, v, dP, T, T, hd, D, ld, Tp, 1, 1, nb, h, T * D, hd, T * ld, hd, h * T * Tp, T * Tp, 1.0, 1, rt.dt)
-    dS = torch.empty_like(P)
+    dS = rt.empty_like(P)
     rt.call("msc_softmax_bwd", dP, P, dS, nb * T, T, Tp, rt.dt)
     # dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
     rt.call("msc_gemm_batched", dS, k, dq, T, hd, T, Tp, ld, ld, 1, 0, nb, h, h * T * Tp, T * Tp, T * ld, hd, T * ld, hd, scale, 0, rt.dt)
@@ -747,7 +747,7 @@ class ChannelFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, scale = ctx.saved_tensors
         rt = ctx.rt
-        dx = torch.empty_like(x)
+        dx = rt.empty_like(x)
         rt.call("msc_channel_bwd", dy.contiguous(), x, scale, dx, x.shape[0], x.shape[1], rt.dt)
         return dx, None, None, None, None, None, None, None, None
 
@@ -761,8 +761,8 @@ class PillarFn(torch.autograd.Function):
         cell = 2.0 * rng / G
         # bins of the frame's points by BEV cell (written by the forward, walked again by the backward)
         sorted_pts = rt.f32(B * Np, 4)
-        cell_start = torch.empty(L.query("msc_pillar_index_bytes", B, G) // 4, dtype=torch.int32, device=points.device)
-        rank = torch.empty(B * Np, dtype=torch.int32, device=points.device)
+        cell_start = rt.alloc((L.query("msc_pillar_index_bytes", B, G) // 4,), torch.int32)
+        rank = rt.alloc((B * Np,), torch.int32)
         out = rt.empty(B, G, G, C)
         rt.call("msc_pillar_fwd", points, w.p, b.p, sorted_pts, cell_start, rank, out, B, Np, G, C, -rng, cell, rt.dt)
         ctx.save_for_backward(sorted_pts, cell_start)

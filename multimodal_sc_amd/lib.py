@@ -93,6 +93,7 @@ def stream_ptr():
 
 _FN = {}
 _SCALARS = (int, float, bool)
+_REC = None     # active replay.Recorder (None: not recording)
 
 
 def _dev(a):
@@ -105,9 +106,12 @@ def call(name: str, *args):
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(lib.load(), name)
-    rc = fn(*[a if (a.__class__ in _SCALARS or a is None) else _dev(a) for a in args])
+    conv = [a if (a.__class__ in _SCALARS or a is None) else _dev(a) for a in args]
+    rc = fn(*conv)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {lib.load().msc_strerror(rc).decode()} (code {rc})")
+    if _REC is not None:
+        _REC.add(name, conv, args)
     return rc
 
 

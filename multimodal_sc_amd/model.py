@@ -309,11 +309,11 @@ class MultimodalSC:
             # the two stacks of (often chip-underfilling) conv kernels overlap; autograd replays the backward of each
             # node on the stream its forward ran on, so the backward overlaps the same way.
             main, s2 = torch.cuda.current_stream(rt.device), rt.branch_stream()
-            s2.wait_stream(main)
+            rt.stream_wait(s2.cuda_stream, main.cuda_stream)
             with torch.cuda.stream(s2):
                 bev_tok = self.bev_encoder(points)
             img_tok = self.image_encoder(image)
-            main.wait_stream(s2)
+            rt.stream_wait(main.cuda_stream, s2.cuda_stream)
             if not torch.cuda.is_current_stream_capturing():
                 bev_tok.record_stream(main)
         else:
@@ -421,7 +421,7 @@ class MultimodalSC:
                 mid_ready = True
             i = 1 if mid_ready else self._bev_slot
             main, s2 = torch.cuda.current_stream(rt.device), rt._branch
-            s2.wait_stream(main)
+            rt.stream_wait(s2.cuda_stream, main.cuda_stream)
             if not torch.cuda.is_current_stream_capturing():
                 grads[i].record_stream(s2)
             with torch.cuda.stream(s2):
@@ -433,7 +433,7 @@ class MultimodalSC:
         self._enc_out = self._enc_in = None
         rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them
         if rt._branch is not None:
-            torch.cuda.current_stream(rt.device).wait_stream(rt._branch)
+            rt.stream_wait(rt.stream, rt._branch.cuda_stream)
 
     def loss_and_grads(self, out, image, ppo=None, backward=True, lower=True):
         """Fused loss kernels produce the loss terms AND d(loss)/d(head), d(loss)/d(patches); autograd then runs
@@ -443,14 +443,14 @@ class MultimodalSC:
         g, P = cfg.recon_grid, cfg.patch
         n_el = 3 * cfg.img_size * cfg.img_size
         sse = rt.f32(B)
-        dpat = torch.empty_like(out["patches"])
+        dpat = rt.empty_like(out["patches"])
         ws = rt.workspace("recon_loss", L.query("msc_recon_loss_workspace_bytes", B))
         rt.call("msc_recon_loss", out["patches"], image, sse, dpat, ws, B, g, P, 2.0 * cfg.recon_weight / (B * n_el), rt.dt)
         terms = {"sse": sse}
         dhead = None
         if ppo is not None:
             t = rt.f32(4)
-            dhead = torch.empty_like(out["head"])
+            dhead = rt.empty_like(out["head"])
             rt.call("msc_ppo_loss", out["head"], ppo["actions"], ppo["old_logp"], ppo["adv"], ppo["ret"], t, dhead, B,
                     cfg.n_actions, HEAD_PAD, cfg.clip_eps, cfg.c_value, cfg.c_entropy, rt.dt)
             terms["ppo"] = t

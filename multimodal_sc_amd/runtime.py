@@ -33,6 +33,43 @@ class ParamRef:
 _raw_stream = torch._C._cuda_getCurrentRawStream
 
 
+class Arena:
+    """Per-step bump allocator for activations: 2 GiB chunks of HBM (never freed), a bump pointer that Trainer.step resets at the
+    start of every step.  The same sequence of allocations therefore returns the same device addresses step after step — what
+    lets a recorded launch list be replayed (multimodal_sc_amd/replay.py) — and nothing is handed back and re-used inside a
+    step, so no buffer of a step can be re-used while another stream still reads it.  Sized for 288 GB of HBM: a 64-frame C3
+    step keeps every activation of the step (~10 GB) instead of recycling them."""
+    CHUNK = 1 << 31
+    ALIGN = 256
+
+    def __init__(self, device):
+        self.device = device
+        self.chunks = []
+        self.ci = self.off = 0
+        self.peak = 0
+
+    def reset(self):
+        self.ci = self.off = 0
+
+    def alloc(self, shape, dtype):
+        n = dtype.itemsize
+        for s in shape:
+            n *= s
+        n_al = (max(n, 1) + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        while True:
+            if self.ci == len(self.chunks):
+                self.chunks.append(torch.empty(max(self.CHUNK, n_al), dtype=torch.uint8, device=self.device))
+            c = self.chunks[self.ci]
+            if self.off + n_al <= c.numel():
+                break
+            self.ci += 1
+            self.off = 0
+        t = c[self.off:self.off + n].view(dtype).view(shape)
+        self.off += n_al
+        self.peak = max(self.peak, self.ci * self.CHUNK + self.off)
+        return t
+
+
 class Runtime:
     def __init__(self, dtype: str = "bf16", device: str = "cuda:0"):
         assert dtype in ("bf16", "f32")
@@ -46,6 +83,9 @@ class Runtime:
         self.side_also_waits = None  # (raw stream, event): call_side() also orders the side stream behind that stream
         self._chain = None           # chain_b(): raw BEV-branch stream + the three events of the fusion's second chain
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
+        self.arena = None            # Arena while a Trainer step runs in replay mode (else torch's caching allocator)
+        self.ws_grew = False         # a workspace was (re)allocated since the flag was cleared (a recorded step must not see that)
+        self._wait_events = {}       # (waiter, signaler) raw stream handles -> reusable event of stream_wait()
         self.host_counters = True    # step / noise-draw numbers as host arguments; Trainer turns it off for hipGraph replay,
                                      # where they must be device-side counters (one tiny kernel each per step)
         self.taps = None             # dict -> conv_bn_fwd records the post-ReLU output of every conv+BN+ReLU by weight name (tests)
@@ -65,11 +105,33 @@ class Runtime:
         """raw hipStream_t of torch's current stream (the C-level query: this runs once per kernel launch)"""
         return _raw_stream(self._dev_index)
 
+    def alloc(self, shape, dtype):
+        """every per-step device buffer of the path comes from here: the step's bump arena when one is active (replay mode),
+        else torch's caching allocator"""
+        if self.arena is not None:
+            return self.arena.alloc(tuple(shape), dtype)
+        return torch.empty(tuple(shape), dtype=dtype, device=self.device)
+
     def empty(self, *shape, dtype=None):
-        return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
+        return self.alloc(shape, dtype or self.tdtype)
 
     def f32(self, *shape):
-        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+        return self.alloc(shape, torch.float32)
+
+    def empty_like(self, t):
+        return self.alloc(t.shape, t.dtype)
+
+    def stream_wait(self, waiter: int, signaler: int):
+        """`waiter` waits for everything enqueued so far on `signaler` (raw hipStream_t handles): event record + stream wait
+        through the C-ABI, so the dependency is part of a recorded launch list (torch's Stream.wait_stream would not be)"""
+        if waiter == signaler:
+            return
+        ev = self._wait_events.get((waiter, signaler))
+        if ev is None:
+            ev = self._wait_events[(waiter, signaler)] = L.query("msc_event_create")
+            if not ev:
+                raise RuntimeError("msc_event_create failed")
+        L.call("msc_stream_wait_stream", waiter, signaler, ev)
 
     def workspace(self, name: str, nbytes: int, per_stream: bool = True) -> torch.Tensor:
         """Persistent fp32 scratch, grown on demand.  One buffer per (name, HIP stream): the encoder branches run on
@@ -83,6 +145,7 @@ class Runtime:
         if t is None or t.numel() < n:
             t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
             self._ws[key] = t
+            self.ws_grew = True
         return t
 
     def branch_stream(self):
@@ -160,7 +223,7 @@ class Runtime:
 
     def join_side(self):
         if self.side is not None and self._side_dirty:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self.stream_wait(self.stream, self._side_raw)
             self._side_dirty = False
             self._side_keep.clear()
 

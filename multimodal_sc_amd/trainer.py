@@ -1,8 +1,13 @@
 """Trainer.step: forward -> fused losses -> kernel backward chain -> DP gradient all-reduce (RCCL) -> fused Adam.
 
-Host loop: EAGER multi-stream launches are the default.  One training step is a few hundred kernel launches on three
-HIP streams (main chain, weight-gradient side stream, LiDAR/BEV branch); the host enqueues them faster than the GPU
-executes them (tools/host_overhead.py), so the GPU never waits for Python.
+Host loop: one training step is ~300 C-ABI calls (~450 kernel launches) on three HIP streams (main chain, weight-gradient
+side stream, LiDAR/BEV branch).  Default = LAUNCH REPLAY (MSC_REPLAY=0 turns it off): two eager warm-up steps, then one eager
+step is RECORDED (every C-ABI call with its argument values, stream handle and event waits; activations come from a per-step
+bump arena, so the addresses repeat) and every later step re-issues that list from C (csrc/replay.hip) — one ctypes call per
+segment instead of ~12 us of Python per launch; segments end where the host must act (the DP all-reduces).  Same kernels, same
+streams, same order: bit-identical to the eager loop (tests/test_model_gpu.py::test_launch_replay_matches_eager).  A step with a
+different batch signature or learning rate records its own program.  Tensors a step returns (loss terms) live in the arena and
+are valid until the next step starts.
 hipGraph capture of the step is implemented and bit-identical to eager, but OPT-IN (MSC_HIP_GRAPH=1) because it measured
 SLOWER on this stack (MI355X, ROCm 7.2, C3 @ 64 frames: replay 10.6 ms/step vs eager 9.7): the replay does not run the
 captured branches concurrently.  With the knob set, after two eager warm-up steps the step is captured once and replayed:
@@ -33,6 +38,8 @@ import torch
 import torch.distributed as dist
 
 from .model import MultimodalSC
+from .replay import Program, Recorder
+from .runtime import Arena
 
 
 def bucket_bounds(total: int, n_buckets: int, align: int = 64):
@@ -127,6 +134,12 @@ class Trainer:
             # pays for the boundary (one GPU: 8.12 -> 8.25 ms); two-piece, non-overlapped and hipGraph DP keep the uncut trunk
             model._img_cut = 3
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
+        self.use_replay = os.environ.get("MSC_REPLAY", "1") != "0" and not self.use_graph
+        if self.use_replay:
+            model.rt.host_counters = False     # as for hipGraph replay: step / noise-draw numbers on the device
+        self._arena = None        # runtime.Arena of this trainer's steps (replay mode)
+        self._programs = {}       # batch signature -> {"seen": eager steps so far, "prog": Program, "static": batch, "terms": ...}
+        self._rec = None          # active Recorder while a step is being recorded
         self.exchange = None      # GradExchange, built on the first multi-rank step (needs the model's mid offset)
         self._seen = 0
         self._graphs = None       # (gA, gB, gC) once captured
@@ -158,12 +171,21 @@ class Trainer:
         not held up and NO further stream is created: with five or more streams active the HIP runtime on this stack
         serialises badly (measured: a third side stream took the step from 9.1 to 16 ms)."""
         m, rt = self.model, self.model.rt
-        s2, main = rt._branch, torch.cuda.current_stream(rt.device)
-        s2.wait_stream(main)
+        s2 = rt._branch
+        rt.stream_wait(s2.cuda_stream, rt.stream)
         if rt.side is not None:
-            s2.wait_stream(rt.side)
-        with torch.cuda.stream(s2):
-            return self.exchange.start(m.params.G, "mid")
+            rt.stream_wait(s2.cuda_stream, rt._side_raw)
+        self._cut("mid")
+        return self._act_mid()
+
+    def _act_mid(self):
+        with torch.cuda.stream(self.model.rt._branch):
+            return self.exchange.start(self.model.params.G, "mid")
+
+    def _cut(self, label):
+        """end of a replay segment: the host acts here (label names the action that follows); no-op unless a step is being recorded"""
+        if self._rec is not None:
+            self._rec.cut(label)
 
     def _adam(self):
         # the upper half of the parameters (transformer / codec / heads) is updated on the side stream: that update then
@@ -180,20 +202,104 @@ class Trainer:
                 self.exchange = GradExchange(G.numel(), self.split, m.mid_offset(), self.dp_pieces)
             ex = self.exchange
             ex.begin_step()
+            self._cut("upper")
             works = [ex.start(G, "upper")]
             # on_mid fires only when the encoder backward really ran its first two phases separately (C1 has no BEV
             # branch: two pieces); "rest" then ends at mid, else at split — GradExchange.bounds tracks which
             m.backward_lower(on_mid=(lambda: works.append(self._allreduce_mid())) if ex.mid is not None else None)
-            works.append(ex.start(G, "rest"))
-            assert ex.covered(), ex.log
-            for w in works:
-                w.wait()
+            self._cut("rest")
+            self._act_rest(works)
         else:
             _, terms = self.forward_backward(batch)
-            for w in allreduce_flat(G, self.n_buckets):
-                w.wait()
+            self._cut("flat")
+            self._act_flat()
         self._adam()
         return terms
+
+    def _act_rest(self, works):
+        ex = self.exchange
+        works.append(ex.start(self.model.params.G, "rest"))
+        assert ex.covered(), ex.log
+        for w in works:
+            w.wait()
+
+    def _act_flat(self):
+        for w in allreduce_flat(self.model.params.G, self.n_buckets):
+            w.wait()
+
+    # ------------------------------------------------------------------ launch replay (default host loop)
+    @staticmethod
+    def _signature(batch, prefix=""):
+        sig = []
+        for k in sorted(batch):
+            v = batch[k]
+            if isinstance(v, dict):
+                sig += Trainer._signature(v, prefix + k + ".")
+            elif torch.is_tensor(v):
+                sig.append((prefix + k, tuple(v.shape), str(v.dtype), v.data_ptr() % 16))
+            else:
+                sig.append((prefix + k, repr(v)))        # None (in-kernel noise) vs a tensor changes the launch arguments
+        return tuple(sig) if not prefix else sig
+
+    def _replay_step(self, batch):
+        rt = self.model.rt
+        key = (self._signature(batch), float(self.lr), self.use_ppo)
+        st = self._programs.get(key)
+        if st is None:
+            st = self._programs[key] = {"seen": 0, "prog": None, "static": None, "terms": None}
+        if self._arena is None:
+            self._arena = Arena(rt.device)
+        if st["prog"] is not None:
+            return self._run_program(batch, st)
+        self._arena.reset()
+        rt.arena = self._arena
+        try:
+            st["seen"] += 1
+            if st["seen"] <= 2:                  # warm-up: workspaces reach their size, streams and events exist
+                return self._eager_step(batch)
+            # the recorded launches read the batch from buffers the trainer owns (the caller's tensors stay the caller's)
+            static = self._clone_batch(batch)
+            rt.ws_grew = False
+            with Recorder() as rec:
+                self._rec = rec
+                try:
+                    terms = self._eager_step(static)
+                finally:
+                    self._rec = None
+            if rt.ws_grew:                       # a workspace moved during the step: its old address is in the list — record again
+                return terms
+            st["prog"], st["static"], st["terms"] = Program(rec), static, terms
+            return terms
+        finally:
+            rt.arena = None
+
+    @staticmethod
+    def _clone_batch(batch):
+        return {k: (Trainer._clone_batch(v) if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v)) for k, v in batch.items()}
+
+    def _run_program(self, batch, st):
+        # the batch goes into the static input buffers the recorded launches read (55 MB device-to-device at 64 frames: ~25 us)
+        dst = dict(_flatten(st["static"]))
+        for k, v in _flatten(batch):
+            dst[k].copy_(v, non_blocking=True)
+        prog = st["prog"]
+        self.model.rt._side_dirty = True         # the step leaves work on the side stream (upper half of the optimizer update)
+        if prog.n_segments == 1:
+            prog.run(-1)
+            return st["terms"]
+        works = []
+        for i, label in enumerate(prog.labels):
+            prog.run(i)
+            if label == "upper":
+                self.exchange.begin_step()
+                works = [self.exchange.start(self.model.params.G, "upper")]
+            elif label == "mid":
+                works.append(self._act_mid())
+            elif label == "rest":
+                self._act_rest(works)
+            elif label == "flat":
+                self._act_flat()
+        return st["terms"]
 
     # ------------------------------------------------------------------ hipGraph capture / replay
     def _capture(self, batch):
@@ -251,7 +357,11 @@ class Trainer:
 
     def step(self, batch):
         """One optimisation step on this rank's shard of the batch; returns the (device-side) loss terms."""
-        if not self.use_graph or self.model.rt.profile is not None:
+        if self.model.rt.profile is not None or self.model.rt.taps is not None:
+            return self._eager_step(batch)
+        if self.use_replay:
+            return self._replay_step(batch)
+        if not self.use_graph:
             return self._eager_step(batch)
         if self._graphs is None:
             self._seen += 1

