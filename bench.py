@@ -159,6 +159,46 @@ def cpu_baseline(cfg_name, seconds_budget=80.0):
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} host cpus, no optimizer step"}
 
 
+def host_inputs_leg(args, cfg, model, trainer, dev_batch, ms_device_resident):
+    """--host-inputs: the same step fed from a HOST-resident frame source (multimodal_sc_amd/frames.py): camera frames as uint8
+    bytes + fp32 clouds + ego state in ordinary host memory -> pinned ring (filler thread) -> H2D of batch k+1 on the
+    weight-gradient side stream while step k runs -> decoded on the main stream at the start of step k+1.  Reported beside
+    `value` (which stays the device-resident number, as the contract says)."""
+    import numpy as np
+    import torch
+    from multimodal_sc_amd.frames import FrameStager
+    B, nb = args.batch, 8
+    rng = np.random.default_rng(0)
+    src = {"camera": rng.integers(0, 256, size=(nb * B, cfg.img_size, cfg.img_size, 3), dtype=np.uint8)}
+    if cfg.use_lidar:
+        src["lidar"] = dev_batch["points"].cpu().numpy().repeat(nb, 0)
+    if cfg.use_state:
+        src["ego"] = dev_batch["state"].cpu().numpy().repeat(nb, 0)
+    ppo = {k: v.cpu().numpy() for k, v in dev_batch["ppo"].items()}
+    st = FrameStager(model.rt, src, B, extra_fn=lambda k: ppo)
+
+    def step():
+        b = st.next()
+        st.prefetch()
+        feed = {k: b[k] for k in ("image", "points", "state") if k in b}        # same keys as the device-resident batch
+        feed.update(snr_db=dev_batch["snr_db"], noise=None, fading=None, ppo=dict(b["extra"]))
+        return trainer.step(feed)
+
+    for _ in range(max(args.warmup, 4)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st.close()
+    ms = 1e3 * dt / args.steps
+    return {"value": B * args.steps / dt, "unit": "frames/s", "ms_per_step": ms, "vs_device_resident": ms_device_resident / ms,
+            "h2d_bytes_per_batch": st.bytes_per_batch, "copy_stream": "weight-gradient side stream (hipMemcpyAsync from a pinned ring)",
+            "source": f"host memory ring of {nb} batches: uint8 camera frames + fp32 clouds + ego state"}
+
+
 def allreduce_probe(model, trainer, dist, torch, reps=5):
     """N>1, outside the timed region: each piece of the gradient exchange alone (barrier, `reps` all-reduces, max over
     ranks) -> ms and algorithmic GB/s per rank, so a scaling run explains itself."""
@@ -322,6 +362,9 @@ def main(argv=None):
         result["dp_backend"] = backend
         result["dp_schedule"] = [list(x) for x in trainer.exchange.log] if trainer.exchange is not None else "flat buckets"
         result["allreduce_alone"] = allreduce_probe(model, trainer, dist, torch)
+
+    if args.host_inputs and world == 1:
+        result["host_inputs"] = host_inputs_leg(args, cfg, model, trainer, batch, result["ms_per_step"])
 
     if rank == 0 and not args.no_roofline:
         rt = model.rt

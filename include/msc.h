@@ -45,6 +45,11 @@ int msc_stream_destroy(int64_t stream);
    enqueued so far on `signaler` (hipEventRecord + hipStreamWaitEvent on that event) */
 int64_t msc_event_create(void);
 int msc_stream_wait_stream(void* waiter, void* signaler, int64_t event);
+/* the same in two halves, for a dependency signalled now and waited for later (staged input batches) */
+int msc_event_record(int64_t event, void* stream);
+int msc_stream_wait_event(void* waiter, int64_t event);
+/* HOST-side blocking wait for the work recorded with `event` (frame stager's filler thread only; never part of a step) */
+int msc_event_synchronize(int64_t event);
 /* bytes of fp32 workspace msc_conv2d_wgrad / msc_linear_wgrad need for their split-K slabs */
 int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len);
 
@@ -165,6 +170,12 @@ int msc_colsum(const void* x, float* out, float* ws, int64_t rows, int64_t cols,
  * Layout, pooling, activation-backward, weight preparation, optimizer (all HBM-bound). */
 int msc_image_to_nhwc(const float* img_nchw, void* out, int B, int C, int H, int W, int Cpad, int dtype,
                       void* stream);
+/* Camera frames as stored / received: uint8 RGB pixel-interleaved [B][H][W][3] (device) -> fp32 planes [B][3][H][W] in [0,1]
+ * (IEEE division by 255 — bit-equal to float32(u8) / float32(255)); H*W % 4 == 0.  The fp32 planes are what msc_image_to_nhwc and
+ * msc_recon_loss read.  msc_memcpy_h2d_async: hipMemcpyAsync of `bytes` from pinned HOST memory (src_host) on `stream` — the
+ * staging copy of the next batch (multimodal_sc_amd/frames.py). */
+int msc_frames_u8_to_nchw(const uint8_t* frames_nhwc, float* img_nchw, int B, int H, int W, void* stream);
+int msc_memcpy_h2d_async(void* dst, const void* src_host, int64_t bytes, void* stream);
 int msc_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int K, int S, int P,
                     int dtype, void* stream);
 int msc_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int K, int S, int P,

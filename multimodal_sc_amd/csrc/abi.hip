@@ -42,6 +42,31 @@ extern "C" int msc_stream_wait_stream(void* waiter, void* signaler, int64_t even
   if (hipStreamWaitEvent((hipStream_t)waiter, ev, 0) != hipSuccess) return MSC_ERR_LAUNCH;
   return MSC_OK;
 }
+// host -> device staging of the next batch of frames: hipMemcpyAsync from PINNED host memory on `stream` (the copy engine moves it
+// while the compute streams run; ordered on `stream` like a kernel).  src_host must be page-locked for the copy to be asynchronous.
+extern "C" int msc_memcpy_h2d_async(void* dst, const void* src_host, int64_t bytes, void* stream) {
+  MSC_CHECK_ARG(dst && src_host && bytes > 0);
+  return hipMemcpyAsync(dst, src_host, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
+// the two halves of msc_stream_wait_stream for a dependency that is signalled now and waited for later (the staged batch: the copy
+// is enqueued a step ahead; the consumer must not wait for what the signalling stream was given AFTER the copy)
+extern "C" int msc_event_record(int64_t event, void* stream) {
+  hipEvent_t ev = (hipEvent_t)(intptr_t)event;
+  if (!ev) return MSC_ERR_BAD_ARG;
+  return hipEventRecord(ev, (hipStream_t)stream) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
+// HOST-side wait (the one blocking call of the ABI): returns once the work recorded with `event` has completed — the frame stager's
+// filler thread calls it before it overwrites a pinned buffer whose copy may still be in flight.  Never called from the step.
+extern "C" int msc_event_synchronize(int64_t event) {
+  hipEvent_t ev = (hipEvent_t)(intptr_t)event;
+  if (!ev) return MSC_ERR_BAD_ARG;
+  return hipEventSynchronize(ev) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
+extern "C" int msc_stream_wait_event(void* waiter, int64_t event) {
+  hipEvent_t ev = (hipEvent_t)(intptr_t)event;
+  if (!ev) return MSC_ERR_BAD_ARG;
+  return hipStreamWaitEvent((hipStream_t)waiter, ev, 0) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
 extern "C" int msc_stream_destroy(int64_t stream) {
   return hipStreamDestroy((hipStream_t)(intptr_t)stream) == hipSuccess ? MSC_OK : MSC_ERR_BAD_ARG;
 }

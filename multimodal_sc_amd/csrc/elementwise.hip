@@ -34,6 +34,24 @@ __global__ void image_to_nhwc_kernel(const float* __restrict__ img, T* __restric
   }
 }
 
+// ---------------------------------------------------------------- camera frames as they come off the wire / disk:
+// uint8 RGB, pixel-interleaved [B][H][W][3]  ->  fp32 planes [B][3][H][W] in [0,1] (IEEE division by 255: bit-equal to
+// numpy's float32(u8) / float32(255)).  One thread = 4 consecutive pixels: three aligned 4-byte loads, one float4 store per plane.
+__global__ void frames_u8_to_nchw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, long nquads, long HW) {
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+    const long pix = q * 4, b = pix / HW, p = pix - b * HW;      // HW % 4 == 0: the 4 pixels lie in one frame
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src + pix * 3);
+    const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];               // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    const uint32_t r[4] = {w0 & 255u, (w0 >> 24) & 255u, (w1 >> 16) & 255u, (w2 >> 8) & 255u};
+    const uint32_t g[4] = {(w0 >> 8) & 255u, w1 & 255u, (w1 >> 24) & 255u, (w2 >> 16) & 255u};
+    const uint32_t bl[4] = {(w0 >> 16) & 255u, (w1 >> 8) & 255u, w2 & 255u, (w2 >> 24) & 255u};
+    float* o = dst + b * 3 * HW + p;
+    *reinterpret_cast<float4*>(o) = make_float4(__fdiv_rn((float)r[0], 255.f), __fdiv_rn((float)r[1], 255.f), __fdiv_rn((float)r[2], 255.f), __fdiv_rn((float)r[3], 255.f));
+    *reinterpret_cast<float4*>(o + HW) = make_float4(__fdiv_rn((float)g[0], 255.f), __fdiv_rn((float)g[1], 255.f), __fdiv_rn((float)g[2], 255.f), __fdiv_rn((float)g[3], 255.f));
+    *reinterpret_cast<float4*>(o + 2 * HW) = make_float4(__fdiv_rn((float)bl[0], 255.f), __fdiv_rn((float)bl[1], 255.f), __fdiv_rn((float)bl[2], 255.f), __fdiv_rn((float)bl[3], 255.f));
+  }
+}
+
 // ---------------------------------------------------------------- max-pool (NHWC), argmax kept as uint8 tap id
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int B, int H, int W,
@@ -354,6 +372,14 @@ extern "C" int msc_image_to_nhwc(const float* img_nchw, void* out, int B, int C,
   const long npix = (long)B * H * W;
   DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(ew_blocks(npix)), dim3(256), 0, (hipStream_t)stream,
                                        img_nchw, (T*)out, npix, C, (long)H * W, Cpad));
+  return msc_launch_status();
+}
+
+extern "C" int msc_frames_u8_to_nchw(const uint8_t* frames_nhwc, float* img_nchw, int B, int H, int W, void* stream) {
+  MSC_CHECK_ARG(frames_nhwc && img_nchw && B > 0 && H > 0 && W > 0 && ((long)H * W) % 4 == 0);
+  MSC_CHECK_ARG(((uintptr_t)frames_nhwc & 3) == 0 && ((uintptr_t)img_nchw & 15) == 0);
+  const long nquads = (long)B * H * W / 4;
+  hipLaunchKernelGGL(frames_u8_to_nchw_kernel, dim3(ew_blocks(nquads)), dim3(256), 0, (hipStream_t)stream, frames_nhwc, img_nchw, nquads, (long)H * W);
   return msc_launch_status();
 }
 

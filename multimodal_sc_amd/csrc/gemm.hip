@@ -90,6 +90,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #ifndef GEMM_P256_STAGES
 #define GEMM_P256_STAGES 4
 #endif
+#ifndef GEMM_PP_KB
+#define GEMM_PP_KB 128      // persistent 128x128 (8 waves, TWO workgroups per CU): 2 x 32 KB ring + 16 KB epilogue slab = 80 KB
+#endif
+#ifndef GEMM_PP_STAGES
+#define GEMM_PP_STAGES 2
+#endif
 #define MSCPLAN_NP_KB GEMM_NP_KB
 #include "gemm_plan.h"
 
@@ -1078,6 +1084,22 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
     }
   }
   if (bm > 128 || bn > 128) return MSC_ERR_UNSUPPORTED;
+#ifdef GEMM_P128_BUILD
+  // Persistent 128x128 with TWO workgroups per CU (8 waves, 2 x 32 KB ring + 16 KB slab = 80 KB, grid = 2 x #CUs, loader / storer
+  // wave roles): built and measured in round 3 (profiles/r3_gemm_p128_sweep.txt) — slower than one tile per workgroup on EVERY
+  // shape of the path (qkv 60 vs 51 us, fc1 128 vs 98, bev1 dgrad 355 vs 252; equal only where a launch has fewer tiles than
+  // slots).  Kept behind this build flag (make alt ALT_FLAGS=-DGEMM_P128_BUILD) for the record, not compiled into the product.
+  if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
+    const char* e = getenv("MSC_GEMM_P128");      // A/B knob, read per call
+    const int ntiles = cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int slots = 2 * num_cus();
+    if (bm == 128 && bn == 128 && zs == 1 && p.nsplit == 1 && !p.xcd_split && ntiles > slots && e && atoi(e)) {
+      dim3 grid((unsigned)slots, 1, 1);
+      hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX, GEMM_PP_KB, GEMM_PP_STAGES, true, 512>), grid, dim3(512), 0, st, q);
+      return msc_launch_status();
+    }
+  }
+#endif
   dim3 grid((unsigned)(cdiv(p.M, bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
   // K bytes per step / ring depth / waves of the multi-workgroup kernels (measured per operand mode, tools/gemm_sweep.py):
   // gathered weight gradients (conv wgrad) run best on 64-byte steps x 3 stages x 4 waves (three workgroups per CU);

@@ -688,6 +688,23 @@ class FusionLayerFn(torch.autograd.Function):
         return dx.view(B, T, D), None, None, None
 
 
+class GradTap(torch.autograd.Function):
+    """Autograd boundary of the two-phase backward: forwards x (already detached from its producer's graph) and, in the backward,
+    puts the gradient that arrives into slots[i] — the very tensor the upstream kernel wrote, no copy — and lets nothing flow on.
+    (A detached leaf + .grad would go through AccumulateGrad, which is free to CLONE the gradient with a torch kernel into
+    allocator memory: a launch the recorded step list does not contain, so a replayed step would read a stale gradient.)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, slots, i):
+        ctx.slots, ctx.i = slots, i
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.slots[ctx.i] = dy
+        return None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ tokens / pooling
 class TokensAssemble(torch.autograd.Function):
     @staticmethod

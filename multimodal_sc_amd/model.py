@@ -147,7 +147,7 @@ class MultimodalSC:
         # Data parallel: 3, which is what gives the gradient exchange its mid piece (Trainer sets it when MSC_IMG_CUT is not given).
         self._img_cut_auto = "MSC_IMG_CUT" not in os.environ
         self._img_cut = int(os.environ.get("MSC_IMG_CUT", "4"))
-        self._img_cut_out = self._img_cut_in = None
+        self._img_cut_out = self._img_cut_grad = None
         self._bev_slot = None
         # in-kernel channel noise (throughput mode): Philox key = (channel_seed, channel_rank), counter word = draw_dev, a
         # device-side counter bumped after EVERY forward (training step, rollout or inference alike), so no two forwards
@@ -243,13 +243,14 @@ class MultimodalSC:
             x = F.ConvBNAct.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
                                   P["image_encoder.bn1.bias"], 2, 3, True, False)
             x = F.MaxPool.apply(x, rt, 3, 2, 1)
-        self._img_cut_out = self._img_cut_in = None
+        self._img_cut_out = self._img_cut_grad = None
         for li in range(1, 5):
             if li == self._img_cut + 1 and self.cfg.use_lidar and rt.branch_streams and x.requires_grad:
                 # autograd boundary inside the trunk: backward_lower() runs the layers above it FIRST, so the main stream
                 # has work queued while the host enqueues the whole BEV-branch backward (see backward_lower)
                 self._img_cut_out = x
-                x = self._img_cut_in = x.detach().requires_grad_()
+                self._img_cut_grad = [None]
+                x = F.GradTap.apply(x.detach(), self.anchor, self._img_cut_grad, 0)
             for bi in range(2):
                 has_ds = bi == 0 and li > 1
                 x = F.BasicBlockFn.apply(x, rt, self._block_params(f"image_encoder.layer{li}.{bi}", has_ds), 2 if has_ds else 1)
@@ -325,8 +326,8 @@ class MultimodalSC:
         # gradients before the encoder backward (DP overlap), also across hipGraph replays
         self._enc_out = [t for t in (img_tok, bev_tok, st_tok) if t is not None]
         self._bev_slot = 1 if bev_tok is not None else None
-        self._enc_in = [t.detach().requires_grad_() for t in self._enc_out]
-        it = iter(self._enc_in)
+        self._enc_grads = [None] * len(self._enc_out)       # filled by the taps' backward (phase 1), consumed by backward_lower
+        it = iter([F.GradTap.apply(t.detach(), self.anchor, self._enc_grads, i) for i, t in enumerate(self._enc_out)])
         img_tok = next(it)
         bev_tok = next(it) if bev_tok is not None else None
         st_tok = next(it) if st_tok is not None else None
@@ -400,7 +401,7 @@ class MultimodalSC:
         trunk + state encoder on the main stream, BEV branch on its stream, their weight gradients on the side stream) —
         the trainer starts the all-reduce of that slice there, under the rest of the trunk's backward."""
         rt = self.rt
-        outs, grads = self._enc_out, [t.grad for t in self._enc_in]
+        outs, grads = self._enc_out, list(self._enc_grads)
         if self._bev_slot is not None and rt._branch is not None:
             # Order of enqueueing (the host, not the GPU, paces this part):
             #  1. the top of the camera trunk (above the boundary image_encoder() left) on the main stream — ~0.5 ms of GPU
@@ -411,13 +412,13 @@ class MultimodalSC:
             #     stream it used, which would stall the main stream for the whole BEV backward.
             #  3. the rest of the camera trunk and the state encoder.
             mid_ready = False
-            if self._img_cut_in is not None:
+            if self._img_cut_grad is not None:
                 # (the state encoder — two tiny layers whose parameters sit above mid_offset() — rides along)
                 rest = [j for j in range(len(outs)) if j not in (0, self._bev_slot)]
                 torch.autograd.backward([outs[0]] + [outs[j] for j in rest], [grads[0]] + [grads[j] for j in rest])
                 outs = [self._img_cut_out, outs[self._bev_slot]]
-                grads = [self._img_cut_in.grad, grads[self._bev_slot]]
-                self._img_cut_out = self._img_cut_in = None
+                grads = [self._img_cut_grad[0], grads[self._bev_slot]]
+                self._img_cut_out = self._img_cut_grad = None
                 mid_ready = True
             i = 1 if mid_ready else self._bev_slot
             main, s2 = torch.cuda.current_stream(rt.device), rt._branch
@@ -430,7 +431,7 @@ class MultimodalSC:
             if mid_ready and on_mid is not None:
                 on_mid()
         torch.autograd.backward(outs, grads)
-        self._enc_out = self._enc_in = None
+        self._enc_out = self._enc_grads = None
         rt.join_side()      # the weight-gradient GEMMs ran on the side stream: order the main stream behind them
         if rt._branch is not None:
             rt.stream_wait(rt.stream, rt._branch.cuda_stream)

@@ -80,6 +80,7 @@ class Runtime:
         self._dev_index = self.device.index if self.device.index is not None else 0
         self.accumulate = 0          # 1: parameter-gradient kernels add into G instead of overwriting
         self._ws = {}
+        self._ws_retired = []        # outgrown workspaces (never freed: see workspace())
         self.side_also_waits = None  # (raw stream, event): call_side() also orders the side stream behind that stream
         self._chain = None           # chain_b(): raw BEV-branch stream + the three events of the fusion's second chain
         self.profile = None          # list -> Runtime.call records (name, scalar args, start event, end event)
@@ -143,6 +144,10 @@ class Runtime:
         key = (name, _raw_stream(self._dev_index) if (per_stream or not self.side_active()) else 0)
         t = self._ws.get(key)
         if t is None or t.numel() < n:
+            if t is not None:
+                # a recorded launch list (replay program, hipGraph) may hold the old buffer's address: it stays allocated, so a
+                # program recorded at a smaller shape keeps working in its own (sufficient) scratch
+                self._ws_retired.append(t)
             t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
             self._ws[key] = t
             self.ws_grew = True

@@ -135,6 +135,7 @@ class Trainer:
             model._img_cut = 3
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
         self.use_replay = os.environ.get("MSC_REPLAY", "1") != "0" and not self.use_graph
+        self.replay_warmup = int(os.environ.get("MSC_REPLAY_WARMUP", "2"))   # eager (arena) steps before the recorded one
         if self.use_replay:
             model.rt.host_counters = False     # as for hipGraph replay: step / noise-draw numbers on the device
         self._arena = None        # runtime.Arena of this trainer's steps (replay mode)
@@ -255,7 +256,7 @@ class Trainer:
         rt.arena = self._arena
         try:
             st["seen"] += 1
-            if st["seen"] <= 2:                  # warm-up: workspaces reach their size, streams and events exist
+            if st["seen"] <= self.replay_warmup:  # warm-up: workspaces reach their size, streams and events exist
                 return self._eager_step(batch)
             # the recorded launches read the batch from buffers the trainer owns (the caller's tensors stay the caller's)
             static = self._clone_batch(batch)

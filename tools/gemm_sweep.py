@@ -28,7 +28,9 @@ def timeit(fn, n=10):
 
 
 cases = []   # (name, flops, fn, legal tiles)
-ALL = ["64x64", "64x128", "128x64", "128x128", "256x128", "256x256"]
+ALL = ["64x64", "64x128", "128x64", "128x128", "128x128p", "256x128", "256x256"]     # 128x128p: persistent, two workgroups per CU
+if os.environ.get("SWEEP_TILES"):
+    ALL = os.environ["SWEEP_TILES"].split(",")
 MN = ["64x64", "64x128", "128x64", "128x128"]
 M = B * 306
 for name, N, K in [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), ("fc2", 512, 2048)]:
@@ -79,13 +81,16 @@ for name, fl, fn, tiles in cases:
         for t in res:
             if t == "auto":
                 os.environ.pop("MSC_GEMM_TILE", None)
+                os.environ.pop("MSC_GEMM_P128", None)
             else:
-                os.environ["MSC_GEMM_TILE"] = t
+                os.environ["MSC_GEMM_TILE"] = t.rstrip("p")
+                os.environ["MSC_GEMM_P128"] = "1" if t.endswith("p") else "0"
             try:
                 res[t].append(timeit(fn))
             except RuntimeError:
                 res[t].append(float("inf"))
     os.environ.pop("MSC_GEMM_TILE", None)
+    os.environ.pop("MSC_GEMM_P128", None)
     med = {t: statistics.median(v) for t, v in res.items()}
     best = min((t for t in med if t != "auto"), key=lambda t: med[t])
     tot_def += med["auto"]; tot_best += med[best]

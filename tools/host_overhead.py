@@ -9,11 +9,12 @@ from multimodal_sc_amd.synthetic import synthetic_batch
 cfg = named_config("C3")
 m = MultimodalSC(cfg, "bf16", "cuda:0")
 tr = Trainer(m)
-cb = synthetic_batch(cfg, 64, seed=1)
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
+cb = synthetic_batch(cfg, B, seed=1)
 b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cb.items() if k != "ppo"}
 b["ppo"] = {k: v.cuda() for k, v in cb["ppo"].items()}
 b["noise"] = b["fading"] = None
-for _ in range(3):
+for _ in range(5):          # (replay mode: two eager warm-ups + the recorded step come first)
     tr.step(b)
 torch.cuda.synchronize()
 enq = []
@@ -24,7 +25,7 @@ for _ in range(10):
     enq.append(time.perf_counter() - t)
 torch.cuda.synchronize()
 tot = (time.perf_counter() - t0) / 10
-print(f"host enqueue per step: {1e3*sum(enq)/10:.2f} ms   wall per step: {1e3*tot:.2f} ms")
+print(f"[{B} frames, {'launch replay' if tr.use_replay else 'eager python loop'}] host enqueue per step: {1e3*sum(enq)/10:.2f} ms   wall per step: {1e3*tot:.2f} ms")
 if "--profile" in sys.argv:
     import cProfile, pstats
     pr = cProfile.Profile()
