@@ -157,10 +157,15 @@ int msc_add2_f32(const float* a, const float* b, float* out, int64_t n, int accu
 int msc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int64_t rows, int D, float eps, int dtype, void* stream);
 int64_t msc_layernorm_bwd_workspace_bytes(int64_t rows, int D);
-/* dx = LN-backward(dy) + dadd (dadd optional: gradient arriving over the residual branch) */
+/* dx = LN-backward(dy) + dadd (dadd optional: gradient arriving over the residual branch).  ws receives the per-row-block partials
+ * of dgamma / dbeta; with dgamma == dbeta == NULL they are NOT reduced here: msc_layernorm_bwd_params finishes them (fixed order,
+ * the partials of ws_a then of the optional ws_b = the other half-batch chain) on whatever stream the caller likes — the
+ * parameter gradients are needed by the optimizer only, so the training step keeps that launch off its critical chains. */
 int msc_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       const void* dadd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
                       int accumulate, int dtype, void* stream);
+int msc_layernorm_bwd_params(const float* ws_a, int64_t rows_a, const float* ws_b, int64_t rows_b, int D, float* dgamma,
+                             float* dbeta, int accumulate, void* stream);
 /* out[c] (+)= sum_r x[r][c] — bias and positional-embedding gradients.  ws >= msc_colsum_workspace_bytes(rows, cols) */
 int64_t msc_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int msc_colsum(const void* x, float* out, float* ws, int64_t rows, int64_t cols, int accumulate, int dtype,

@@ -372,7 +372,7 @@ struct Sched { KStep ks; int nk, s_kw0, s_step; };
 // waves per SIMD at two workgroups per CU — measured 3 % faster over the path's shapes, 15-20 % on the weight gradients),
 // 256 (4 waves, 2x2) otherwise.
 template <typename T, int AMODE, int BMODE, int BM, int BN, bool EPX, int KB, int NSTAGE, bool PERSIST, int NTHR>
-__global__ __launch_bounds__(NTHR, (NTHR == 512 && BM == 128 ? 4 : 2)) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 : 2)) void gemm_kernel(const GemmParams p) {
   constexpr int KT = KB / sizeof(T);
   constexpr int NWN = BN == 256 ? 4 : 2;        // waves along N: 256x256 -> 2x4 (wave tile 128x64), 256x128 -> 4x2, else 2x2
   constexpr int NWM = (NTHR / 64) / NWN;        // waves along M
@@ -1073,6 +1073,18 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   static const int cls_il = getenv("MSC_DGRAD_CLS_INTERLEAVE") ? atoi(getenv("MSC_DGRAD_CLS_INTERLEAVE")) : 1;   // A/B knob
   q.cls_interleave = (AMODE == OPM_CONV_DGRAD && p.cls && cls_il && p.nsplit == 1 && p.cMc % bm == 0) ? 1 : 0;
   if (zs > 65535) return MSC_ERR_UNSUPPORTED;
+#ifdef GEMM_NP256_BUILD
+  // one-tile-per-workgroup 256x128 (8 waves, wave tile 64x64, 64-byte K steps x 3 stages = 72 KB: TWO workgroups per CU):
+  // 0.75x the staged bytes and DMA instructions per FLOP of the 128x128 tile.  Experiment build only (MSC_GEMM_NP256=1).
+  if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
+    const char* e = getenv("MSC_GEMM_NP256");
+    if (e && atoi(e) && p.M >= 256 && p.N >= 128 && zs == 1 && p.nsplit == 1 && !p.stats && !p.colsum && !(AMODE == OPM_CONV_DGRAD && p.cls)) {
+      dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, 128)), 1, 1);
+      hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, 64, 3, false, 512>), grid, dim3(512), 0, st, q);
+      return msc_launch_status();
+    }
+  }
+#endif
   if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
     if (bm == 256) {     // persistent: one workgroup per CU walks the tiles
       const int ntiles = cdiv(p.M, 256) * cdiv(p.N, bn);

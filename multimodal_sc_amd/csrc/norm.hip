@@ -20,6 +20,7 @@
 enum { FIN_BN_FWD = 0, FIN_SUMS = 1 };
 struct FinArgs {
   const float* partial; int nblk; int C;
+  const float* partial2; int nblk2;      // optional second partial buffer (FIN_SUMS: the other half-batch chain's rows), summed after the first
   // FIN_BN_FWD
   double inv_count; float eps; const float* gamma; const float* beta; float* mean; float* rstd; float* scale; float* shift;
   // FIN_SUMS
@@ -51,6 +52,10 @@ __global__ __launch_bounds__(256) void finalize2_kernel(const FinArgs a) {
     for (; b < a.nblk; b += RL) {
       s1 += (double)a.partial[(long)b * 2 * a.C + c];
       s2 += (double)a.partial[(long)b * 2 * a.C + a.C + c];
+    }
+    for (b = rl; b < a.nblk2; b += RL) {
+      s1 += (double)a.partial2[(long)b * 2 * a.C + c];
+      s2 += (double)a.partial2[(long)b * 2 * a.C + a.C + c];
     }
   }
   red[0][rl][cl] = s1;
@@ -758,7 +763,7 @@ extern "C" int64_t msc_layernorm_bwd_workspace_bytes(int64_t rows, int D) {
 extern "C" int msc_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
                                  const float* gamma, const void* dadd, void* dx, float* dgamma, float* dbeta, float* ws,
                                  int64_t rows, int D, int accumulate, int dtype, void* stream) {
-  MSC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && rows > 0 && D > 0 && D <= 1024);
+  MSC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && ws && rows > 0 && D > 0 && D <= 1024 && ((dgamma == nullptr) == (dbeta == nullptr)));
   hipStream_t st = (hipStream_t)stream;
   const int nblk = cdiv(rows, LN_ROWS_PER_BLOCK);
   if (dtype == MSC_F32) {
@@ -771,8 +776,22 @@ extern "C" int msc_layernorm_bwd(const void* dy, const void* x, const float* mea
                        mean, rstd, gamma, (const bf16_t*)dadd, (bf16_t*)dx, ws, (long)rows, D);
   } else
     return MSC_ERR_BAD_ARG;
-  // ws holds [nblk][2][D]: first stat = dgamma, second = dbeta
-  launch_fin_sums(ws, nblk, D, nullptr, nullptr, dgamma, dbeta, accumulate, st);
+  // ws holds [nblk][2][D]: first stat = dgamma, second = dbeta.  dgamma == dbeta == NULL: the caller finishes them later, off the
+  // critical chain (msc_layernorm_bwd_params)
+  if (dgamma) launch_fin_sums(ws, nblk, D, nullptr, nullptr, dgamma, dbeta, accumulate, st);
+  return msc_launch_status();
+}
+
+extern "C" int msc_layernorm_bwd_params(const float* ws_a, int64_t rows_a, const float* ws_b, int64_t rows_b, int D, float* dgamma,
+                                        float* dbeta, int accumulate, void* stream) {
+  MSC_CHECK_ARG(ws_a && rows_a > 0 && dgamma && dbeta && D > 0 && D <= 1024 && ((ws_b != nullptr) == (rows_b > 0)));
+  FinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.partial = ws_a; a.nblk = cdiv(rows_a, LN_ROWS_PER_BLOCK); a.C = D;
+  a.partial2 = ws_b; a.nblk2 = ws_b ? cdiv(rows_b, LN_ROWS_PER_BLOCK) : 0;
+  a.acc0 = dgamma; a.acc1 = dbeta; a.accumulate = accumulate;
+  // off the critical chain: many blocks, short per-thread chains
+  hipLaunchKernelGGL((finalize2_kernel<FIN_SUMS, 2>), dim3(cdiv(D, 2)), dim3(256), 0, (hipStream_t)stream, a);
   return msc_launch_status();
 }
 

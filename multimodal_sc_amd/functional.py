@@ -405,8 +405,11 @@ def layernorm_fwd(rt, x2d, g: ParamRef, b: ParamRef):
 def layernorm_bwd(rt, dy2d, x2d, mean, rstd, g: ParamRef, b: ParamRef, dadd=None):
     R, D = x2d.shape
     dx = rt.empty_like(x2d)
-    ws = rt.workspace("ln_bwd", L.query("msc_layernorm_bwd_workspace_bytes", R, D))
-    rt.call("msc_layernorm_bwd", dy2d, x2d, mean, rstd, g.p, dadd, dx, g.g, b.g, ws, R, D, rt.accumulate, rt.dt)
+    # the per-row-block partials of dgamma / dbeta get a buffer of their own (not a shared workspace): their reduction runs on the
+    # side stream, off the critical chain — the parameter gradients are needed by the optimizer only
+    part = rt.f32(L.query("msc_layernorm_bwd_workspace_bytes", R, D) // 4)
+    rt.call("msc_layernorm_bwd", dy2d, x2d, mean, rstd, g.p, dadd, dx, None, None, part, R, D, rt.accumulate, rt.dt)
+    rt.call_side("msc_layernorm_bwd_params", part, R, None, 0, D, g.g, b.g, rt.accumulate)
     return dx
 
 
@@ -577,17 +580,17 @@ def _fusion_bwd_two_chains(ctx, dy):
     dqkv, dh1, dx = rt.empty(M, 3 * D), rt.empty(M, D), rt.empty(M, D)
     delta = rt.f32(*lse.shape)
     Tpad = lse.shape[1]
-    lnt = rt.f32(2, 2, 2 * D)                                      # [chain][ln1 | ln2][dgamma | dbeta]
+    # per-row-block partials of the LayerNorm parameter gradients: [ln1 | ln2][chain] buffers, reduced on the side stream
+    lnp = [[rt.f32(L.query("msc_layernorm_bwd_workspace_bytes", n, D) // 4) for n in ((B // 2) * T, (B - B // 2) * T)] for _ in range(2)]
     scale = 1.0 / math.sqrt(hd)
     if p.get("last", True):                                       # dy comes from the final LayerNorm's backward on the main stream
         L.call("msc_stream_wait_stream", s2, main, ev_ab)
     Bh = B // 2
     chains = ((main, 0, Bh * T, 0, Bh, 0), (s2, Bh * T, (B - Bh) * T, Bh * h, B - Bh, 1))
-    lnws = [rt.workspace(f"ln_bwd_chain{ci}", L.query("msc_layernorm_bwd_workspace_bytes", n, D)).data_ptr() for _, _, n, _, _, ci in chains]
     es = x2d.element_size()
     rD, r3D, rF = D * es, 3 * D * es, Fh * es
     a_x, a_h1, a_qkv, a_o, a_x1, a_h2 = x2d.data_ptr(), h1.data_ptr(), qkv.data_ptr(), o.data_ptr(), x1.data_ptr(), h2.data_ptr()
-    a_upre, a_st, a_lse, a_delta, a_lnt = upre.data_ptr(), st.data_ptr(), lse.data_ptr(), delta.data_ptr(), lnt.data_ptr()
+    a_upre, a_st, a_lse, a_delta = upre.data_ptr(), st.data_ptr(), lse.data_ptr(), delta.data_ptr()
     a_dx2, a_dpre, a_dh2, a_dx1, a_do = dx2.data_ptr(), dpre.data_ptr(), dh2.data_ptr(), dx1.data_ptr(), do.data_ptr()
     a_dqkv, a_dh1, a_dx = dqkv.data_ptr(), dh1.data_ptr(), dx.data_ptr()
     ln1g, ln2g = p["ln1g"].p.data_ptr(), p["ln2g"].p.data_ptr()
@@ -601,14 +604,8 @@ def _fusion_bwd_two_chains(ctx, dy):
         rt.call_side("msc_linear_wgrad", xf, df, w.g, b.g, rt.workspace("wgrad", wsb, per_stream=False), wsb, M, N, K, rt.accumulate, rt.dt)
 
     def ln_sum(k, g, b):
-        if b.off == g.off + D:
-            rt.call_side("msc_add2_f32", lnt[0][k], lnt[1][k], g.g, 2 * D, rt.accumulate)
-        else:
-            rt.call_side("msc_add2_f32", lnt[0][k][:D], lnt[1][k][:D], g.g, D, rt.accumulate)
-            rt.call_side("msc_add2_f32", lnt[0][k][D:], lnt[1][k][D:], b.g, D, rt.accumulate)
-
-    def lnt_ptr(ci, k, half):                                       # lnt[ci][k][half * D:]
-        return a_lnt + ((ci * 2 + k) * 2 * D + half * D) * 4
+        # ONE fixed-order reduction over both chains' partial rows, on the side stream (which waits for both chains)
+        rt.call_side("msc_layernorm_bwd_params", lnp[k][0], chains[0][2], lnp[k][1], chains[1][2], D, g.g, b.g, rt.accumulate)
 
     rt.side_also_waits = (s2, ev_bs)
     try:
@@ -621,7 +618,7 @@ def _fusion_bwd_two_chains(ctx, dy):
             call("msc_linear_dgrad", a_dpre + r0 * rF, t1, None, None, L.ACT_NONE, None, a_dh2 + r0 * rD, n, Fh, D, dt, c)
         for c, r0, n, _, _, ci in chains:
             call("msc_layernorm_bwd", a_dh2 + r0 * rD, a_x1 + r0 * rD, a_st + (2 * M + r0) * 4, a_st + (3 * M + r0) * 4, ln2g, a_dx2 + r0 * rD,
-                 a_dx1 + r0 * rD, lnt_ptr(ci, 1, 0), lnt_ptr(ci, 1, 1), lnws[ci], n, D, 0, dt, c)
+                 a_dx1 + r0 * rD, None, None, lnp[1][ci], n, D, 0, dt, c)
         wgrad(o, dx1, p["projw"], p["projb"])
         ln_sum(1, p["ln2g"], p["ln2b"])
         for c, r0, n, _, _, _ in chains:
@@ -634,7 +631,7 @@ def _fusion_bwd_two_chains(ctx, dy):
             call("msc_linear_dgrad", a_dqkv + r0 * r3D, tq, None, None, L.ACT_NONE, None, a_dh1 + r0 * rD, n, 3 * D, D, dt, c)
         for c, r0, n, _, _, ci in chains:
             call("msc_layernorm_bwd", a_dh1 + r0 * rD, a_x + r0 * rD, a_st + r0 * 4, a_st + (M + r0) * 4, ln1g, a_dx1 + r0 * rD, a_dx + r0 * rD,
-                 lnt_ptr(ci, 0, 0), lnt_ptr(ci, 0, 1), lnws[ci], n, D, 0, dt, c)
+                 None, None, lnp[0][ci], n, D, 0, dt, c)
         ln_sum(0, p["ln1g"], p["ln1b"])
     finally:
         rt.side_also_waits = None
@@ -642,7 +639,7 @@ def _fusion_bwd_two_chains(ctx, dy):
         L.call("msc_stream_wait_stream", main, s2, ev_ba)
     # everything the second chain reads must outlive its kernels: released with the side stream's operands at join_side()
     (rt.capture_keep if torch.cuda.is_current_stream_capturing() else rt._side_keep).append(
-        (x2d, st, h1, qkv, lse, o, x1, h2, upre, u, dx2, dpre, dh2, dx1, do, dqkv, dh1, delta, lnt))
+        (x2d, st, h1, qkv, lse, o, x1, h2, upre, u, dx2, dpre, dh2, dx1, do, dqkv, dh1, delta, lnp))
     return dx.view(B, T, D), None, None, None
 
 

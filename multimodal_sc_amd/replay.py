@@ -45,6 +45,85 @@ class Recorder:
         return False
 
 
+def _streams_of(name, conv):
+    """streams a record is ordered on: a kernel launch -> its stream (last argument); msc_stream_wait_stream -> waiter AND signaler
+    (it must keep its place in both streams' sequences: it captures what the signaler has been given so far); the split event
+    calls (record now / wait later, paired through the event) -> None = ordered against everything"""
+    if name == "msc_stream_wait_stream":
+        return (conv[0] or 0, conv[1] or 0)
+    if name in ("msc_event_record", "msc_stream_wait_event", "msc_event_synchronize"):
+        return None
+    return (conv[-1] or 0,)
+
+
+def reorder(recs, policy):
+    """A different ENQUEUE order of the same launches: per-stream order and every cross-stream dependency are kept (so the GPU
+    sees the same per-stream programs and waits), only the order in which the host hands them to the streams changes.  The
+    eager loop's order is what Python produced — e.g. the whole BEV-branch backward before the first launch of the camera
+    trunk's backward; a replayed list can feed the streams evenly.  policy: "recorded" | "rr" (round-robin one launch at a time
+    among the streams with an emittable launch) | "main" (the main stream first; others only when it waits for them)."""
+    if policy == "recorded":
+        return recs
+    out, seg = [], []
+
+    def flush():
+        if not seg:
+            return
+        order = []                     # streams in order of first appearance: the main stream launches first in every segment
+        queues = {}
+        glob = []                      # indices of records ordered against everything
+        for i, (name, conv) in enumerate(seg):
+            st = _streams_of(name, conv)
+            if st is None:
+                glob.append(i)
+                continue
+            for s in st:
+                if s not in queues:
+                    queues[s] = []
+                    order.append(s)
+                queues[s].append(i)
+        head = {s: 0 for s in order}
+        done = [False] * len(seg)
+        gi = 0
+        emitted = 0
+        rr = 0
+
+        def emittable(i):
+            if gi < len(glob) and i > glob[gi]:
+                return False           # a globally ordered record comes first
+            st = _streams_of(*seg[i])
+            return all(queues[s][head[s]] == i for s in st)
+
+        while emitted < len(seg):
+            if gi < len(glob) and all(done[j] for j in range(glob[gi])):
+                i = glob[gi]
+                gi += 1
+            else:
+                cand = [s for s in order if head[s] < len(queues[s]) and emittable(queues[s][head[s]])]
+                assert cand, "reorder: no emittable record (cycle?)"
+                if policy == "main":
+                    s = cand[0]
+                else:
+                    s = cand[rr % len(cand)]
+                    rr += 1
+                i = queues[s][head[s]]
+                for t in _streams_of(*seg[i]):
+                    head[t] += 1
+            done[i] = True
+            out.append(seg[i])
+            emitted += 1
+        seg.clear()
+
+    for r in recs:
+        if r[0] == "__cut__":
+            flush()
+            out.append(r)
+        else:
+            seg.append(r)
+    flush()
+    return out
+
+
 class Program:
     """the recorded launch list on the C side; run(segment) re-issues it"""
 
@@ -58,7 +137,19 @@ class Program:
         self.labels = []            # labels[i] = the host action after segment i (None after the last)
         self.names = []
         ids = {}
-        for name, conv in rec.recs:
+        import os
+        self.order = os.environ.get("MSC_REPLAY_ORDER", "recorded")
+        ordered = reorder(rec.recs, self.order)
+        if os.environ.get("MSC_REPLAY_DUMP"):       # debugging aid: the launch list as text (entry point, streams, scalar arguments)
+            with open(os.environ["MSC_REPLAY_DUMP"], "a") as fh:
+                fh.write(f"# program of {len(ordered)} records, order={self.order}\n")
+                for name, conv in ordered:
+                    if name == "__cut__":
+                        fh.write(f"---- cut: {conv}\n")
+                    else:
+                        st = _streams_of(name, conv)
+                        fh.write(f"{name:34s} streams={[hex(s) for s in st] if st else 'all'} scalars={[a for a in conv[:-1] if isinstance(a, (int, float)) and abs(a) < 1 << 32]}\n")
+        for name, conv in ordered:
             if name == "__cut__":
                 lib.msc_replay_cut(self.handle)
                 self.labels.append(conv)

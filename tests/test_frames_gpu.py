@@ -51,8 +51,9 @@ def test_staged_batches_equal_the_source_bytes_and_feed_the_step(cuda, tmp_path)
                 batch = {"image": b["image"], "points": b["points"], "state": b["state"], "snr_db": snr, "noise": None, "fading": None,
                          "ppo": dict(b["extra"])}
             else:
-                cam = torch.from_numpy(np.ascontiguousarray(log.arrays["camera"][idx])).cuda()
-                batch = {"image": (cam.float() / 255.0).permute(0, 3, 1, 2).contiguous(),
+                # (numpy's IEEE division; torch's `tensor / 255.0` on the device multiplies by the reciprocal: 1 ulp off)
+                cam = np.asarray(log.arrays["camera"][idx]).astype(np.float32) / np.float32(255)
+                batch = {"image": torch.from_numpy(np.ascontiguousarray(cam.transpose(0, 3, 1, 2))).cuda(),
                          "points": torch.from_numpy(np.ascontiguousarray(log.arrays["lidar"][idx])).cuda(),
                          "state": torch.from_numpy(np.ascontiguousarray(log.arrays["ego"][idx])).cuda(), "snr_db": snr, "noise": None,
                          "fading": None, "ppo": {kk: torch.from_numpy(v).cuda() for kk, v in ppo_host[k].items()}}

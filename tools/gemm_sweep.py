@@ -82,15 +82,18 @@ for name, fl, fn, tiles in cases:
             if t == "auto":
                 os.environ.pop("MSC_GEMM_TILE", None)
                 os.environ.pop("MSC_GEMM_P128", None)
+                os.environ.pop("MSC_GEMM_NP256", None)
             else:
-                os.environ["MSC_GEMM_TILE"] = t.rstrip("p")
+                os.environ["MSC_GEMM_TILE"] = t.rstrip("pn")
                 os.environ["MSC_GEMM_P128"] = "1" if t.endswith("p") else "0"
+                os.environ["MSC_GEMM_NP256"] = "1" if t.endswith("n") else "0"      # 256x128n: experiment build (make alt)
             try:
                 res[t].append(timeit(fn))
             except RuntimeError:
                 res[t].append(float("inf"))
     os.environ.pop("MSC_GEMM_TILE", None)
     os.environ.pop("MSC_GEMM_P128", None)
+    os.environ.pop("MSC_GEMM_NP256", None)
     med = {t: statistics.median(v) for t, v in res.items()}
     best = min((t for t in med if t != "auto"), key=lambda t: med[t])
     tot_def += med["auto"]; tot_best += med[best]

@@ -36,6 +36,12 @@ print(f"main stream: {len(mrows)} kernels, busy {sum(E(r) - S(r) for r in mrows)
       f"(median {sorted(g for g, _, _ in gaps)[len(gaps) // 2] / 1e3:.1f} us)")
 for g, a, b in sorted(gaps, reverse=True)[:12]:
     print(f"   gap {g / 1e3:7.1f} us  after {a}  before {b}")
+# what the other streams were doing during the largest main-stream gap
+gl = sorted(((S(b) - E(a), E(a), S(b)) for a, b in zip(mrows, mrows[1:])), reverse=True)[0]
+print(f"largest gap [{(gl[1] - t0) / 1e3:.0f} us .. {(gl[2] - t0) / 1e3:.0f} us of the step]: kernels of the other streams inside it")
+for r in step:
+    if r['Stream_Id'] != main and E(r) > gl[1] and S(r) < gl[2]:
+        print(f"     stream {r['Stream_Id']}  {(S(r) - gl[1]) / 1e3:8.1f} .. {(E(r) - gl[1]) / 1e3:8.1f} us  {name(r)}")
 # overlap share per main-stream kernel family
 others = sorted((S(r), E(r)) for r in step if r['Stream_Id'] != main)
 def overlap(a, b):
