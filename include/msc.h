@@ -69,10 +69,14 @@ int64_t msc_conv2d_splitk_workspace_bytes(int64_t rows_out, int cols_out, int64_
 int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_partial, int B, int H, int W,
                    int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype,
                    void* stream);
-/* dx:[B,H,W,Cin] = conv-transpose of dy:[B,Ho,Wo,Cout] with wt:[Cin,KH,KW,Cout] (msc_permute3_cast)
- * + res (optional T [B,H,W,Cin]: the gradient arriving over a residual/identity branch). */
-int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, void* dx, int B, int H, int W, int Cin,
-                     int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream);
+/* dx:[B,H,W,Cin] = ( conv-transpose of dy:[B,Ho,Wo,Cout] with wt:[Cin,KH,KW,Cout] (msc_permute3_cast)
+ *                    + res ) * [relu_ref > 0]
+ * res (optional T [B,H,W,Cin]): the gradient arriving over a residual/identity branch.
+ * relu_ref (optional T [B,H,W,Cin]): this layer's INPUT when that input is the output of a ReLU — the ReLU's backward is applied
+ * here, in the epilogue (or the split-K finish), so the producer of that input receives an already masked gradient and neither
+ * re-reads its activation for the mask nor writes a separate masked copy for its identity branch. */
+int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, const void* relu_ref, void* dx, int B, int H, int W,
+                     int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream);
 /* dw (fp32, OHWI) = sum over pixels dy^T x.  accumulate!=0 adds to dw.  ws: see msc_wgrad_workspace_bytes. */
 int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,
                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,

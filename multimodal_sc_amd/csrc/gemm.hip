@@ -52,6 +52,8 @@ struct GemmParams {
   int xcd_split;                // split-K launches: all tiles of one K slice on one XCD (see the kernel's index mapping)
   const void* dref; int dact;   // epilogue: multiply by act'(dref[m][n]) (fused activation backward)
   float* colsum;                // epilogue: per-row-block column sums of the stored output, [tile_m][N]
+  int dephase_first;            // ... and the number of workgroups that make up round 1
+  int dephase;                  // GEMM_DEPHASE experiment build: s_sleep units (64 clk) the odd residency slot of each CU waits in round 1
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
@@ -574,6 +576,19 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
 #ifdef GEMM_STAMP
   unsigned long long st_entry = STAMP_NOW(), st_wait = 0, st_k = 0, st_ep = 0, st_first, st_tiles = 0, st_steps = 0;
 #endif
+#ifdef GEMM_DEPHASE
+  // Experiment: the two workgroups resident on a CU start round 1 together and then run K loop (LDS-bound) and epilogue (store
+  // burst) in phase.  HW_ID.TG_ID (bits 19:16) is the workgroup's slot on its CU: the odd slot of the FIRST round (the first
+  // 2 x #CUs workgroups in launch order) sleeps once; every later workgroup inherits its slot's phase.
+  if constexpr (!PERSIST) {
+    if (p.dephase > 0 && (int)(blockIdx.z * gridDim.x + blockIdx.x) < p.dephase_first) {
+      const unsigned hwid = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);     // HW_REG_HW_ID, offset 16, size 4 = TG_ID
+      if (hwid & 1u) {
+        for (int i = 0; i < p.dephase; ++i) __builtin_amdgcn_s_sleep(16);     // 1024 clocks per unit
+      }
+    }
+  }
+#endif
   issue_begin_tile(iw);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue_step();
@@ -989,7 +1004,8 @@ __global__ __launch_bounds__(64 * RY) void splitk_reduce_kernel(const float* __r
 // Block = 64 columns x RB rows: thread (c4 = 4 columns, rl = one of 16 row lanes); fixed summation order everywhere.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int ns, long M, int N, T* __restrict__ y,
-                                                            const T* __restrict__ res, float* __restrict__ stats, int RB) {
+                                                            const T* __restrict__ res, float* __restrict__ stats, int RB,
+                                                            const T* __restrict__ relu_ref) {
   __shared__ float red[2][16][64];
   const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + c4 * 4;
@@ -1011,6 +1027,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
       if (res) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += msc_traits<T>::ld(res + e + j);
+      }
+      if (relu_ref) {     // dgrad: ReLU backward of the activation that produced this layer's input (relu_ref = that activation)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = msc_traits<T>::ld(relu_ref + e + j) > 0.f ? v[j] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) msc_traits<T>::st(y + e + j, v[j]);
@@ -1072,6 +1092,13 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   GemmParams q = p;
   static const int cls_il = getenv("MSC_DGRAD_CLS_INTERLEAVE") ? atoi(getenv("MSC_DGRAD_CLS_INTERLEAVE")) : 1;   // A/B knob
   q.cls_interleave = (AMODE == OPM_CONV_DGRAD && p.cls && cls_il && p.nsplit == 1 && p.cMc % bm == 0) ? 1 : 0;
+#ifdef GEMM_DEPHASE
+  {
+    const char* e = getenv("MSC_GEMM_DEPHASE");      // units of 1024 clocks (s_sleep 16); 0 = off
+    q.dephase = e ? atoi(e) : 0;
+    q.dephase_first = 2 * num_cus();
+  }
+#endif
   if (zs > 65535) return MSC_ERR_UNSUPPORTED;
 #ifdef GEMM_NP256_BUILD
   // one-tile-per-workgroup 256x128 (8 waves, wave tile 64x64, 64-byte K steps x 3 stages = 72 KB: TWO workgroups per CU):
@@ -1200,10 +1227,19 @@ static int set_conv_geom(GemmParams& p, int B, int H, int W, int C, int Ho, int 
 // shared tail of msc_conv2d_fwd / msc_conv2d_dgrad: split-K launch + finish when it pays and the workspace allows
 template <int AMODE>
 static int launch_conv_maybe_split(GemmParams& p, void* out, const void* res, float* stats, float* ws, int64_t ws_bytes, int dtype,
-                                   hipStream_t st) {
+                                   hipStream_t st, const void* relu_ref = nullptr) {
   mscplan::ConvSplit cs = mscplan::conv_split(p.M, p.N, p.K, dtype == MSC_F32);
   if (AMODE == OPM_CONV_DGRAD && p.cls) cs.ns = 1;
-  if (cs.ns <= 1 || !ws || ws_bytes < (int64_t)cs.ns * p.M * p.N * 4) return launch_gemm_dt<AMODE, OPM_DENSE_K>(p, 1, dtype, st);
+  if (cs.ns <= 1 || !ws || ws_bytes < (int64_t)cs.ns * p.M * p.N * 4) {
+    if constexpr (AMODE == OPM_CONV_DGRAD) {
+      if (relu_ref) {      // un-split: the extended epilogue multiplies by relu'(relu_ref) after the residual add
+        p.dref = relu_ref;
+        p.dact = MSC_ACT_RELU;
+        return launch_gemm_dt<AMODE, OPM_DENSE_K, true>(p, 1, dtype, st);
+      }
+    }
+    return launch_gemm_dt<AMODE, OPM_DENSE_K>(p, 1, dtype, st);
+  }
   const int tps = cs.tps, ns = cs.ns;
   const int bm0 = tile_for(p.M, p.N, 1, AMODE, OPM_DENSE_K, dtype).bm;   // row granularity of the BatchNorm partials the caller sized its buffer for
   p.nsplit = ns;
@@ -1214,9 +1250,11 @@ static int launch_conv_maybe_split(GemmParams& p, void* out, const void* res, fl
   if (rc != MSC_OK) return rc;
   const dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, bm0));
   if (dtype == MSC_F32)
-    hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (float*)out, (const float*)res, stats, bm0);
+    hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (float*)out, (const float*)res, stats, bm0,
+                       (const float*)relu_ref);
   else
-    hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (bf16_t*)out, (const bf16_t*)res, stats, bm0);
+    hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (bf16_t*)out, (const bf16_t*)res, stats, bm0,
+                       (const bf16_t*)relu_ref);
   return msc_launch_status();
 }
 
@@ -1236,8 +1274,8 @@ extern "C" int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_p
   return launch_conv_maybe_split<OPM_CONV_FWD>(p, y, nullptr, bn_partial, ws, ws_bytes, dtype, (hipStream_t)stream);
 }
 
-extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, void* dx, int B, int H, int W, int Cin,
-                                int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream) {
+extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, const void* relu_ref, void* dx, int B, int H, int W,
+                                int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && wt && dx && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(Cout >= vec_of(dtype) && ilog2_exact(Cout) >= 0 && Cin > 0 && ilog2_exact(stride) >= 0);
@@ -1260,7 +1298,7 @@ extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res,
     // class — measured 67 -> 32 us)
     if (p.cMc % 128 != 0 && p.cMc % 64 == 0) p.bm_cap = 64;
   }
-  return launch_conv_maybe_split<OPM_CONV_DGRAD>(p, dx, res, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream);
+  return launch_conv_maybe_split<OPM_CONV_DGRAD>(p, dx, res, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream, relu_ref);
 }
 
 extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,

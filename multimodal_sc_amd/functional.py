@@ -53,8 +53,9 @@ _FUSED_BIAS = os.environ.get("MSC_FUSED_BIAS", "1") != "0"    # A/B knob: 0 = bi
 
 
 def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad,
-                relu, want_dres, need_dx, dx_res=None, had_res=False):
+                relu, want_dres, need_dx, dx_res=None, had_res=False, dx_relu_ref=None):
     """-> (dx or None, dres or None).  dx_res: extra gradient w.r.t. x added inside the dgrad epilogue.
+    dx_relu_ref: x itself when x is the output of a ReLU whose backward belongs to the PRODUCER of x: applied in the dgrad epilogue.
     stats: [4,C] mean, rstd, scale, shift of the forward.  had_res: the forward added a residual before the ReLU (the mask
     then has to come from y; otherwise it is rebuilt from y_raw*scale+shift and y is not read)."""
     B, H, W, Cin = x.shape
@@ -84,7 +85,7 @@ def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: Para
         dx = rt.empty_like(x)
         wsd = L.query("msc_conv2d_splitk_workspace_bytes", B * H * W, Cin, KH * KW * Cout, rt.dt) if stride == 1 else 0
         ws = rt.workspace("conv_splitk", wsd) if wsd else None
-        rt.call("msc_conv2d_dgrad", d_raw, conv.t, dx_res, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsd, rt.dt)
+        rt.call("msc_conv2d_dgrad", d_raw, conv.t, dx_res, dx_relu_ref, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsd, rt.dt)
     return dx, dres
 
 
@@ -163,8 +164,12 @@ class BasicBlockFn(torch.autograd.Function):
     """ResNet BasicBlock as ONE autograd node: conv-bn-relu, conv-bn, (+1x1 conv-bn identity), add, relu."""
 
     @staticmethod
-    def forward(ctx, x, rt, p, stride):
+    def forward(ctx, x, rt, p, stride, mask_in=False, dy_masked=False):
         # p: dict of ParamRefs: conv1,bn1g,bn1b,conv2,bn2g,bn2b[,dconv,dbng,dbnb]
+        # mask_in: x is the previous block's output (post-ReLU) and that block expects an already masked gradient: this block's
+        #   dgrad epilogue applies relu'(x).  dy_masked: the next block does the same for THIS block's output, so the gradient that
+        #   arrives is dz = dy * [y > 0] already: bn2's backward needs no mask (y is not read) and the identity branch's gradient
+        #   is the incoming tensor itself (no masked copy is written)
         o1, o1_raw, st1 = conv_bn_fwd(rt, x, None, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True)
         has_ds = "dconv" in p
         if has_ds:
@@ -176,24 +181,31 @@ class BasicBlockFn(torch.autograd.Function):
         if has_ds:
             saved += [idt_raw, std]
         ctx.save_for_backward(*saved)
-        ctx.cfg = (rt, p, stride, has_ds)
+        ctx.cfg = (rt, p, stride, has_ds, mask_in, dy_masked)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        rt, p, stride, has_ds = ctx.cfg
+        rt, p, stride, has_ds, mask_in, dy_masked = ctx.cfg
         sv = ctx.saved_tensors
         x, o1_raw, o1, st1, o2_raw, y, st2 = sv[:7]
-        # conv2/bn2: dres = gradient of the identity branch (post-ReLU mask, which needs y: the residual was added before the ReLU)
-        do1, didt = conv_bn_bwd(rt, dy.contiguous(), o1, o2_raw, y, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True, True, True,
-                                had_res=True)
+        dy = dy.contiguous()
+        if dy_masked:
+            # the consumer's dgrad epilogue already applied this block's output ReLU: BatchNorm backward without a mask, identity = dy
+            do1, _ = conv_bn_bwd(rt, dy, o1, o2_raw, None, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, False, False, True)
+            didt = dy
+        else:
+            # conv2/bn2: dres = gradient of the identity branch (post-ReLU mask, which needs y: the residual was added before the ReLU)
+            do1, didt = conv_bn_bwd(rt, dy, o1, o2_raw, y, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True, True, True,
+                                    had_res=True)
         if has_ds:
             idt_raw, std = sv[7:]
             dx_id, _ = conv_bn_bwd(rt, didt, x, idt_raw, None, std, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False, False, True)
         else:
             dx_id = didt
-        dx, _ = conv_bn_bwd(rt, do1, x, o1_raw, o1, st1, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True, False, True, dx_res=dx_id)
-        return dx, None, None, None
+        dx, _ = conv_bn_bwd(rt, do1, x, o1_raw, o1, st1, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True, False, True, dx_res=dx_id,
+                            dx_relu_ref=x if mask_in else None)
+        return dx, None, None, None, None, None
 
 
 class MaxPool(torch.autograd.Function):

@@ -75,6 +75,7 @@ def named_config(name: str) -> MSCConfig:
     return MSCConfig(**table[name])
 
 
+_PREMASK = os.environ.get("MSC_BLOCK_PREMASK", "1") != "0"    # A/B knob: 0 = every block masks its own output gradient (bn_bwd reads y)
 HEAD_PAD = 16   # policy logits (n_actions) + value (1) packed and zero-padded to 16 output rows
 IMG_CPAD = 8    # RGB padded to 8 channels so every implicit-GEMM K chunk is a full 16-byte vector
 
@@ -253,7 +254,11 @@ class MultimodalSC:
                 x = F.GradTap.apply(x.detach(), self.anchor, self._img_cut_grad, 0)
             for bi in range(2):
                 has_ds = bi == 0 and li > 1
-                x = F.BasicBlockFn.apply(x, rt, self._block_params(f"image_encoder.layer{li}.{bi}", has_ds), 2 if has_ds else 1)
+                # the ReLU backward of a block's output is applied by the NEXT block's dgrad epilogue (functional.BasicBlockFn):
+                # every block but the first masks its input's gradient, every block but the last receives a masked one
+                first, last = (li, bi) == (1, 0), (li, bi) == (4, 1)
+                x = F.BasicBlockFn.apply(x, rt, self._block_params(f"image_encoder.layer{li}.{bi}", has_ds), 2 if has_ds else 1,
+                                         not first and _PREMASK, not last and _PREMASK)
         return x.view(B, -1, x.shape[-1])
 
     def bev_encoder(self, points):

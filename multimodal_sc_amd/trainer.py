@@ -138,6 +138,12 @@ class Trainer:
         self.replay_warmup = int(os.environ.get("MSC_REPLAY_WARMUP", "2"))   # eager (arena) steps before the recorded one
         if self.use_replay:
             model.rt.host_counters = False     # as for hipGraph replay: step / noise-draw numbers on the device
+        self._main = None
+        if os.environ.get("MSC_MAIN_PRIO"):      # experiment knob: +1 = highest priority of the device for the main chain
+            from . import lib as L
+            with torch.cuda.device(model.rt.device):
+                h = L.query("msc_stream_create", int(os.environ["MSC_MAIN_PRIO"]))
+            self._main = torch.cuda.ExternalStream(h, device=model.rt.device)
         self._arena = None        # runtime.Arena of this trainer's steps (replay mode)
         self._programs = {}       # batch signature -> {"seen": eager steps so far, "prog": Program, "static": batch, "terms": ...}
         self._rec = None          # active Recorder while a step is being recorded
@@ -358,6 +364,18 @@ class Trainer:
 
     def step(self, batch):
         """One optimisation step on this rank's shard of the batch; returns the (device-side) loss terms."""
+        if self._main is None:
+            return self._step(batch)
+        # MSC_MAIN_PRIO: the step's main chain on a stream of its own priority instead of the caller's (default) stream
+        rt = self.model.rt
+        cur = torch.cuda.current_stream(rt.device)
+        rt.stream_wait(self._main.cuda_stream, cur.cuda_stream)
+        with torch.cuda.stream(self._main):
+            out = self._step(batch)
+        rt.stream_wait(cur.cuda_stream, self._main.cuda_stream)
+        return out
+
+    def _step(self, batch):
         if self.model.rt.profile is not None or self.model.rt.taps is not None:
             return self._eager_step(batch)
         if self.use_replay:

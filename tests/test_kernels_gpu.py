@@ -268,8 +268,33 @@ def test_persistent_conv_fwd_dgrad(rts, monkeypatch, tile, case):
     ref.backward(q(dy, "bf16").permute(0, 3, 1, 2))
     dx = torch.full((B, H, W, Cin), float("nan"), device=rt.device, dtype=rt.tdtype)
     # dgrad output has Cin columns: the 256-column tile needs Cin >= 256, else the knob falls back inside choose_tile's rules
-    rt.call("msc_conv2d_dgrad", dev(dy, rt), Wp.t, dev(rs, rt), dx, B, H, W, Cin, Cout, K, K, s, p, None, 0, rt.dt)
+    rt.call("msc_conv2d_dgrad", dev(dy, rt), Wp.t, dev(rs, rt), None, dx, B, H, W, Cin, Cout, K, K, s, p, None, 0, rt.dt)
     check("dx", dx, xq.grad + q(rs, "bf16"), tol("bf16") * 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 14, 14, 64, 64, 3, 1, 1), (3, 7, 7, 256, 512, 3, 1, 1), (2, 14, 14, 64, 128, 3, 2, 1), (2, 14, 14, 64, 128, 1, 2, 0)])
+def test_conv_dgrad_relu_ref(rts, dtype, case):
+    """msc_conv2d_dgrad with relu_ref: dx = (conv-transpose(dy) + res) * [relu_ref > 0], bit-identical to masking the plain result
+    (the mask is a 0/1 multiply of the value that is rounded either way) — un-split epilogue, split-K finish (7x7x256) and the
+    strided / class-major row order."""
+    from multimodal_sc_amd import lib as L
+    rt = rts[dtype]
+    B, H, W, Cin, Cout, K, s, p = case
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    w = rnd(Cout, K, K, Cin, seed=1, scale=0.1)
+    Wp = FakeParam(rt, w, "conv")
+    dy, rs, ref = dev(rnd(B, Ho, Wo, Cout, seed=2), rt), dev(rnd(B, H, W, Cin, seed=3), rt), dev(rnd(B, H, W, Cin, seed=4), rt)
+    ref[0, 0, 0, :4] = 0                                     # exact zeros: relu'(0) = 0
+    wsb = L.query("msc_conv2d_splitk_workspace_bytes", B * H * W, Cin, K * K * Cout, rt.dt) if s == 1 else 0
+    ws = torch.empty(max(wsb // 4, 1), device=rt.device) if wsb else None
+    plain = torch.empty(B, H, W, Cin, device=rt.device, dtype=rt.tdtype)
+    masked = torch.full_like(plain, float("nan"))
+    rt.call("msc_conv2d_dgrad", dy, Wp.t, rs, None, plain, B, H, W, Cin, Cout, K, K, s, p, ws, wsb, rt.dt)
+    rt.call("msc_conv2d_dgrad", dy, Wp.t, rs, ref, masked, B, H, W, Cin, Cout, K, K, s, p, ws, wsb, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(masked, torch.where(ref > 0, plain, torch.zeros_like(plain)))
+    assert (masked[0, 0, 0, :4] == 0).all() and masked.abs().max() > 0
 
 
 # ------------------------------------------------------------------------------------------------ conv + BN
@@ -406,6 +431,48 @@ def test_basic_block(rts, dtype, stride):
     for k in p:
         if k in vec:
             check_grad("d" + k, p[k].g, tv[k].grad, tol(dtype, True) * 16, dtype, True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(4, 12, 64, 64, 1), (4, 12, 64, 128, 2), (3, 7, 256, 256, 1)])
+def test_block_chain_premasked_gradient_is_bitwise_the_same(rts, dtype, shape):
+    """Two BasicBlocks in a row.  With the pre-mask flags the SECOND block's dgrad epilogue (or split-K finish: the 7x7x256 case)
+    applies the first block's output ReLU backward, and the first block skips its mask and the masked copy for its identity
+    branch.  (dgrad + res) * [y > 0] is rounded once either way, so every gradient must be BIT-identical to the unflagged chain."""
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    B, H, C0, C1, s2 = shape
+    x = rnd(B, H, H, C0, seed=1)
+    def params(cin, cout, stride, seed):
+        ws = {"conv1": rnd(cout, 3, 3, cin, seed=seed, scale=0.05), "conv2": rnd(cout, 3, 3, cout, seed=seed + 1, scale=0.05)}
+        if stride == 2:
+            ws["dconv"] = rnd(cout, 1, 1, cin, seed=seed + 2, scale=0.1)
+        vec = {k: (1 + 0.1 * rnd(cout, seed=seed + 10 + i)) if k.endswith("g") else 0.1 * rnd(cout, seed=seed + 20 + i)
+               for i, k in enumerate(["bn1g", "bn1b", "bn2g", "bn2b"] + (["dbng", "dbnb"] if stride == 2 else []))}
+        return ws, vec
+    res = []
+    dy = None
+    for flags in (False, True):
+        ps = []
+        for cin, cout, st, seed in ((C0, C0, 1, 100), (C0, C1, s2, 200)):
+            ws, vec = params(cin, cout, st, seed)
+            p = {k: FakeParam(rt, v, "conv") for k, v in ws.items()}
+            p.update({k: FakeParam(rt, v, "vec") for k, v in vec.items()})
+            ps.append((p, st))
+        xd = dev(x, rt).requires_grad_()
+        h = F.BasicBlockFn.apply(xd, rt, ps[0][0], ps[0][1], False, flags)
+        y = F.BasicBlockFn.apply(h, rt, ps[1][0], ps[1][1], flags, False)
+        if dy is None:
+            dy = dev(rnd(*y.shape, seed=7), rt)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        rt.join_side()
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), xd.grad.clone(), [pp.g.clone() for p, _ in ps for pp in p.values()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][1].abs().max() > 0
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -65,7 +65,7 @@ for name, H, Cin, Cout, K, s, p in convs:
         wt, dx = rnd(Cin, K, K, Cout), rnd(B, H, H, Cin)
         wsd = L.query("msc_conv2d_splitk_workspace_bytes", B * H * H, Cin, K * K * Cout, rt.dt) if s == 1 else 0
         wsg = torch.empty(max(wsd // 4, 1), device=dev) if wsd else None
-        t = timeit(lambda: rt.call("msc_conv2d_dgrad", y, wt, None, dx, B, H, H, Cin, Cout, K, K, s, p, wsg, wsd, rt.dt))
+        t = timeit(lambda: rt.call("msc_conv2d_dgrad", y, wt, None, None, dx, B, H, H, Cin, Cout, K, K, s, p, wsg, wsd, rt.dt))
         rows.append((f"conv_dgrad {name}", t, fl))
     dw = torch.empty(Cout, K, K, Cin, device=dev)
     wsb = L.query("msc_wgrad_workspace_bytes", Cout, K * K * Cin, B * Ho * Ho)

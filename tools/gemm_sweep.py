@@ -64,7 +64,7 @@ for name, H, Cin, Cout, K, s, p in convs:
         wt, dx = rnd(Cin, K, K, Cout), rnd(B, H, H, Cin)
         wsg = torch.empty(8 * B * H * H * Cin, device=dev)
         cases.append((f"conv_dgrad {name}", fl, (lambda y=y, wt=wt, dx=dx, wsg=wsg, H=H, Cin=Cin, Cout=Cout, K=K, s=s, p=p:
-                      rt.call("msc_conv2d_dgrad", y, wt, None, dx, B, H, H, Cin, Cout, K, K, s, p, wsg if s == 1 else None, wsg.numel() * 4 if s == 1 else 0, rt.dt)), ALL))
+                      rt.call("msc_conv2d_dgrad", y, wt, None, None, dx, B, H, H, Cin, Cout, K, K, s, p, wsg if s == 1 else None, wsg.numel() * 4 if s == 1 else 0, rt.dt)), ALL))
     dw = torch.empty(Cout, K, K, Cin, device=dev)
     wsb = L.query("msc_wgrad_workspace_bytes", Cout, K * K * Cin, B * Ho * Ho) * 4
     ws = torch.empty(wsb // 4, device=dev)

@@ -33,7 +33,7 @@ for dt in ("f32", "bf16"):
             dx = torch.zeros(B, H, H, Cin, dtype=rt.tdtype, device="cuda")
             wsd = L.query("msc_conv2d_splitk_workspace_bytes", B * H * H, Cin, 9 * Cout, rt.dt) if use else 0
             ws = torch.empty(max(wsd // 4, 1), device="cuda") if wsd else None
-            rt.call("msc_conv2d_dgrad", dyt, wt, res, dx, B, H, H, Cin, Cout, 3, 3, s, 1, ws, wsd, rt.dt)
+            rt.call("msc_conv2d_dgrad", dyt, wt, res, None, dx, B, H, H, Cin, Cout, 3, 3, s, 1, ws, wsd, rt.dt)
             torch.cuda.synchronize()
             douts.append(dx.float())
         print("   dgrad wsd", wsd, "max|d|", (douts[1] - douts[0]).abs().max().item(), "ref max", douts[0].abs().max().item())
