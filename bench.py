@@ -78,6 +78,10 @@ def gemm_flops(name, s):
         return conv(*s[:9])
     if name == "msc_conv2d_wgrad":
         return conv(*s[1:10])
+    if name == "msc_stem_s2d_conv_fwd":        # scalars: B, Hs, Ws, Cout, dtype — the real 7x7x3 taps
+        return 2.0 * s[0] * s[1] * s[2] * s[3] * 147
+    if name == "msc_stem_s2d_conv_wgrad":      # scalars: ws_bytes, B, Hs, Ws, Cout, accumulate, dtype
+        return 2.0 * s[1] * s[2] * s[3] * s[4] * 147
     if name == "msc_linear_fwd":
         return 2.0 * s[0] * s[1] * s[2]
     if name == "msc_linear_dgrad":      # scalars: dact, M, N, K, dtype
@@ -99,6 +103,10 @@ def gemm_bytes(name, s):
         return conv(*s[:9], 2.0)
     if name == "msc_conv2d_wgrad":
         return conv(*s[1:10], 4.0)
+    if name == "msc_stem_s2d_conv_fwd":
+        return 2.0 * s[0] * s[1] * s[2] * 16 + 2.0 * s[0] * s[1] * s[2] * s[3] + 2.0 * s[3] * 256
+    if name == "msc_stem_s2d_conv_wgrad":
+        return 2.0 * s[1] * s[2] * s[3] * 16 + 2.0 * s[1] * s[2] * s[3] * s[4] + 4.0 * s[4] * 256
     if name == "msc_linear_fwd":
         M, N, K = s[0], s[1], s[2]
         return 2.0 * (M * K + N * K + M * N)

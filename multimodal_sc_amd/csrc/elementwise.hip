@@ -34,6 +34,66 @@ __global__ void image_to_nhwc_kernel(const float* __restrict__ img, T* __restric
   }
 }
 
+// ---------------------------------------------------------------- stem in space-to-depth form (see csrc/gemm.hip msc_stem_s2d_*)
+// image NCHW fp32 [B][3][H][W] -> T [B][H/2][W/2][16], channel (dy*2+dx)*3 + c holds pixel (2i+dy, 2j+dx); channels 12..15 = 0
+template <typename T>
+__global__ void image_to_s2d_kernel(const float* __restrict__ img, T* __restrict__ out, long ncell, int H, int W) {
+  const int Hs = H >> 1, Ws = W >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Ws);
+    const long t = i / Ws;
+    const int r = (int)(t % Hs);
+    const long b = t / Hs;
+    float v[16];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float2 px = *reinterpret_cast<const float2*>(img + ((b * 3 + c) * H + 2 * r + dy) * (long)W + 2 * j);   // dx = 0, 1
+        v[(dy * 2 + 0) * 3 + c] = px.x;
+        v[(dy * 2 + 1) * 3 + c] = px.y;
+      }
+    v[12] = v[13] = v[14] = v[15] = 0.f;
+    constexpr int VEC = msc_traits<T>::VEC;
+#pragma unroll
+    for (int c0 = 0; c0 < 16; c0 += VEC) {
+      vecf<T> o;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o.v[k] = v[c0 + k];
+      o.store(out + i * 16 + c0);
+    }
+  }
+}
+// conv1 weights fp32 [Cout][7][7][8] (OHWI, RGB in channels 0..2) -> T [Cout][4][4][16]: tap (i, dy) of the re-blocked kernel is
+// original row kh = 2i + dy - 1 (kh = -1: the zero row that pads 7 to 8), same for columns
+template <typename T>
+__global__ void stem_weight_s2d_kernel(const float* __restrict__ w7, T* __restrict__ out, int Cout) {
+  const int n = Cout * 256;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int ch = e & 15, jj = (e >> 4) & 3, ii = (e >> 6) & 3, o = e >> 8;
+    float v = 0.f;
+    if (ch < 12) {
+      const int q = ch / 3, c = ch - 3 * q, dy = q >> 1, dx = q & 1;
+      const int kh = 2 * ii + dy - 1, kw = 2 * jj + dx - 1;
+      if (kh >= 0 && kw >= 0) v = w7[((o * 7 + kh) * 7 + kw) * 8 + c];
+    }
+    msc_traits<T>::st(out + e, v);
+  }
+}
+// weight gradient back: dw7 [Cout][7][7][8] (+)= gather of dw_s2d [Cout][4][4][16] (padded channels 3..7 get 0)
+__global__ void stem_wgrad_unpack_kernel(const float* __restrict__ dws, float* __restrict__ dw7, int Cout, int accumulate) {
+  const int n = Cout * 7 * 7 * 8;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int c = e & 7, t = e >> 3, kw = t % 7, kh = (t / 7) % 7, o = t / 49;
+    float v = 0.f;
+    if (c < 3) {
+      const int ii = (kh + 1) >> 1, dy = (kh + 1) & 1, jj = (kw + 1) >> 1, dx = (kw + 1) & 1;
+      v = dws[((o * 4 + ii) * 4 + jj) * 16 + (dy * 2 + dx) * 3 + c];
+    }
+    dw7[e] = (accumulate ? dw7[e] : 0.f) + v;
+  }
+}
+
 // ---------------------------------------------------------------- camera frames as they come off the wire / disk:
 // uint8 RGB, pixel-interleaved [B][H][W][3]  ->  fp32 planes [B][3][H][W] in [0,1] (IEEE division by 255: bit-equal to
 // numpy's float32(u8) / float32(255)).  One thread = 4 consecutive pixels: three aligned 4-byte loads, one float4 store per plane.
@@ -372,6 +432,23 @@ extern "C" int msc_image_to_nhwc(const float* img_nchw, void* out, int B, int C,
   const long npix = (long)B * H * W;
   DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(ew_blocks(npix)), dim3(256), 0, (hipStream_t)stream,
                                        img_nchw, (T*)out, npix, C, (long)H * W, Cpad));
+  return msc_launch_status();
+}
+
+extern "C" int msc_image_to_s2d(const float* img_nchw, void* out, int B, int H, int W, int dtype, void* stream) {
+  MSC_CHECK_ARG(img_nchw && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ((uintptr_t)img_nchw & 7) == 0);
+  const long ncell = (long)B * (H / 2) * (W / 2);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_s2d_kernel<T>, dim3(ew_blocks(ncell)), dim3(256), 0, (hipStream_t)stream, img_nchw, (T*)out, ncell, H, W));
+  return msc_launch_status();
+}
+extern "C" int msc_stem_weight_s2d(const float* w7, void* w_s2d, int Cout, int dtype, void* stream) {
+  MSC_CHECK_ARG(w7 && w_s2d && Cout > 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_weight_s2d_kernel<T>, dim3(ew_blocks((long)Cout * 256)), dim3(256), 0, (hipStream_t)stream, w7, (T*)w_s2d, Cout));
+  return msc_launch_status();
+}
+extern "C" int msc_stem_wgrad_unpack(const float* dw_s2d, float* dw7, int Cout, int accumulate, void* stream) {
+  MSC_CHECK_ARG(dw_s2d && dw7 && Cout > 0);
+  hipLaunchKernelGGL(stem_wgrad_unpack_kernel, dim3(ew_blocks((long)Cout * 392)), dim3(256), 0, (hipStream_t)stream, dw_s2d, dw7, Cout, accumulate);
   return msc_launch_status();
 }
 

@@ -1274,6 +1274,41 @@ extern "C" int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_p
   return launch_conv_maybe_split<OPM_CONV_FWD>(p, y, nullptr, bn_partial, ws, ws_bytes, dtype, (hipStream_t)stream);
 }
 
+// ---- ImageEncoder stem in space-to-depth form.  The 7x7 / stride-2 / pad-3 convolution over RGB padded to 8 channels spends
+// 62 % of its MFMA work and staged bytes on zero channels (K = 7*7*8 = 392 for 147 real taps).  With the image re-blocked as
+// [B][H/2][W/2][(dy,dx,c) = 12 -> 16] the same convolution is a 4x4 / stride-1 one over 16 channels (K = 256, 57 % real): output
+// row ho reads re-blocked rows ho-2 .. ho+1 (pad 2 before, 1 after — the output size is passed explicitly, the gather's bounds
+// check supplies the padding).  Weights in that layout come from msc_stem_weight_s2d, the weight gradient goes back through
+// msc_stem_wgrad_unpack (csrc/elementwise.hip).
+static int stem_geom(GemmParams& p, int B, int Hs, int Ws) { return set_conv_geom(p, B, Hs, Ws, 16, Hs, Ws, 4, 4, 1, 2); }
+
+extern "C" int msc_stem_s2d_conv_fwd(const void* xs, const void* w_s2d, void* y, float* bn_partial, int B, int Hs, int Ws, int Cout,
+                                     int dtype, void* stream) {
+  MSC_CHECK_ARG(xs && w_s2d && y && B > 0 && Hs > 0 && Ws > 0 && Cout > 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  if (!fits32((long)B * Hs * Ws * 16, dtype)) return MSC_ERR_UNSUPPORTED;
+  GemmParams p = base_params();
+  p.A = xs; p.B = w_s2d; p.C = y; p.stats = bn_partial;
+  p.M = B * Hs * Ws; p.N = Cout; p.K = 256;
+  p.ldb = p.K; p.ldc = Cout;
+  if (stem_geom(p, B, Hs, Ws) != MSC_OK) return MSC_ERR_BAD_ARG;
+  return launch_gemm_dt<OPM_CONV_FWD, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
+}
+
+extern "C" int msc_stem_s2d_conv_wgrad(const void* xs, const void* dy, float* dw_s2d, float* ws, int64_t ws_bytes, int B, int Hs, int Ws,
+                                       int Cout, int accumulate, int dtype, void* stream) {
+  MSC_CHECK_ARG(xs && dy && dw_s2d && B > 0 && Hs > 0 && Ws > 0 && Cout % vec_of(dtype) == 0);
+  MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
+  if (!fits32((long)B * Hs * Ws * 16, dtype) || !fits32((long)B * Hs * Ws * Cout, dtype)) return MSC_ERR_UNSUPPORTED;
+  GemmParams p = base_params();
+  p.A = dy; p.B = xs;
+  p.M = Cout; p.N = 256; p.K = B * Hs * Ws;
+  p.lda = Cout;
+  if (stem_geom(p, B, Hs, Ws) != MSC_OK) return MSC_ERR_BAD_ARG;
+  return finish_wgrad(p, dw_s2d, nullptr, ws, ws_bytes, p.K, accumulate, dtype, (hipStream_t)stream,
+                      launch_gemm_dt<OPM_DENSE_MN, OPM_CONV_WGRAD>, 64);
+}
+
 extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, const void* relu_ref, void* dx, int B, int H, int W,
                                 int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && wt && dx && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);

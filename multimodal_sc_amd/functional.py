@@ -49,6 +49,7 @@ def conv_bn_fwd(rt: Runtime, x, res, conv: ParamRef, gamma: ParamRef, beta: Para
 _STEM_WGRAD_MAIN = os.environ.get("MSC_STEM_WGRAD_MAIN", "1") != "0"
 _MASK_FROM_X = os.environ.get("MSC_BN_MASK_FROM_X", "1") != "0"   # A/B knob: 0 = BatchNorm backward reads y for every ReLU mask
 _FUSED_STEM = os.environ.get("MSC_FUSED_STEM", "1") != "0"    # A/B knob: 0 = separate bn_apply / max-pool kernels in the stem
+_STEM_S2D = os.environ.get("MSC_STEM_S2D", "1") != "0"       # A/B knob: 0 = the stem convolution over NHWC with RGB padded to 8 channels
 _FUSED_BIAS = os.environ.get("MSC_FUSED_BIAS", "1") != "0"    # A/B knob: 0 = bias gradients by separate column-sum launches
 
 
@@ -113,17 +114,22 @@ class StemFn(torch.autograd.Function):
     runs the weight gradient.  The stem's input is the image: no data gradient."""
 
     @staticmethod
-    def forward(ctx, x, anchor, rt, conv, gamma, beta, stride, pad, pK, pS, pP):
+    def forward(ctx, x, anchor, rt, conv, gamma, beta, stride, pad, pK, pS, pP, w_s2d=None):
+        # w_s2d given: x is the image in space-to-depth form [B,H/2,W/2,16] and the 7x7/2 convolution runs as a 4x4/1 one over it
+        # (msc_stem_s2d_conv_*: K = 256 instead of 392, same sums); else x is NHWC with RGB padded to 8 channels
         B, H, W, Cin = x.shape
         Cout, KH, KW, _ = conv.shape
-        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        Ho, Wo = (H, W) if w_s2d is not None else ((H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1)
         M = B * Ho * Wo
         nblk = L.query("msc_conv2d_fwd_stat_rows", M, Cout, rt.dt)
         y_raw = rt.empty(B, Ho, Wo, Cout)
         partial = rt.workspace("bn_partial", nblk * 2 * Cout * 4)
-        wsb = L.query("msc_conv2d_splitk_workspace_bytes", M, Cout, KH * KW * Cin, rt.dt)
-        ws = rt.workspace("conv_splitk", wsb) if wsb else None
-        rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsb, rt.dt)
+        if w_s2d is not None:
+            rt.call("msc_stem_s2d_conv_fwd", x, w_s2d, y_raw, partial, B, H, W, Cout, rt.dt)
+        else:
+            wsb = L.query("msc_conv2d_splitk_workspace_bytes", M, Cout, KH * KW * Cin, rt.dt)
+            ws = rt.workspace("conv_splitk", wsb) if wsb else None
+            rt.call("msc_conv2d_fwd", x, conv.c, y_raw, partial, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsb, rt.dt)
         stats = rt.f32(4, Cout)
         rt.call("msc_bn_finalize", partial, nblk, Cout, M, BN_EPS, gamma.p, beta.p, stats[0], stats[1], stats[2], stats[3])
         Hp, Wp = (Ho + 2 * pP - pK) // pS + 1, (Wo + 2 * pP - pK) // pS + 1
@@ -136,13 +142,13 @@ class StemFn(torch.autograd.Function):
             rt.call("msc_bn_apply", y_raw, stats[2], stats[3], None, act, M, Cout, 1, rt.dt)
             rt.taps[conv.name] = act
         ctx.save_for_backward(x, y_raw, stats, idx, xsel)
-        ctx.cfg = (rt, conv, gamma, beta, stride, pad, pK, pS, pP)
+        ctx.cfg = (rt, conv, gamma, beta, stride, pad, pK, pS, pP, w_s2d is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y_raw, stats, idx, xsel = ctx.saved_tensors
-        rt, conv, gamma, beta, stride, pad, pK, pS, pP = ctx.cfg
+        rt, conv, gamma, beta, stride, pad, pK, pS, pP, s2d = ctx.cfg
         B, H, W, Cin = x.shape
         Cout, KH, KW, _ = conv.shape
         _, Ho, Wo, _ = y_raw.shape
@@ -150,6 +156,13 @@ class StemFn(torch.autograd.Function):
         ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
         rt.call("msc_bn_relu_pool_bwd", dy.contiguous(), idx, xsel, y_raw, stats[0], stats[1], gamma.p, stats[2], stats[3], d_raw, gamma.g, beta.g,
                 ws, B, Ho, Wo, Cout, pK, pS, pP, rt.accumulate, rt.dt)
+        if s2d:
+            # (the stem is the last node of the backward: its weight gradient runs on the launching stream, see conv_bn_bwd)
+            wsb = L.query("msc_wgrad_workspace_bytes", Cout, 256, B * Ho * Wo)
+            dws = rt.f32(Cout * 256)
+            rt.call("msc_stem_s2d_conv_wgrad", x, d_raw, dws, rt.workspace("wgrad_main", wsb), wsb, B, H, W, Cout, 0, rt.dt)
+            rt.call("msc_stem_wgrad_unpack", dws, conv.g, Cout, rt.accumulate)
+            return (None,) * 12
         wsb = L.query("msc_wgrad_workspace_bytes", Cout, KH * KW * Cin, B * Ho * Wo)
         if _STEM_WGRAD_MAIN:     # last node of the backward: nothing left on the launching stream to hide behind (see conv_bn_bwd)
             rt.call("msc_conv2d_wgrad", x, d_raw, conv.g, rt.workspace("wgrad_main", wsb), wsb, B, H, W, Cin, Cout, KH, KW, stride, pad,
@@ -157,7 +170,7 @@ class StemFn(torch.autograd.Function):
         else:
             rt.call_side("msc_conv2d_wgrad", x, d_raw, conv.g, rt.workspace("wgrad", wsb, per_stream=False), wsb, B, H, W, Cin, Cout, KH, KW,
                          stride, pad, rt.accumulate, rt.dt)
-        return (None,) * 11
+        return (None,) * 12
 
 
 class BasicBlockFn(torch.autograd.Function):

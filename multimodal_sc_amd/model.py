@@ -75,7 +75,7 @@ def named_config(name: str) -> MSCConfig:
     return MSCConfig(**table[name])
 
 
-_PREMASK = os.environ.get("MSC_BLOCK_PREMASK", "1") != "0"    # A/B knob: 0 = every block masks its own output gradient (bn_bwd reads y)
+_PREMASK = os.environ.get("MSC_BLOCK_PREMASK", "0") == "1"    # opt-in (measured +-0 in the step): 1 = the NEXT block's dgrad epilogue applies a block's output ReLU backward
 HEAD_PAD = 16   # policy logits (n_actions) + value (1) packed and zero-padded to 16 output rows
 IMG_CPAD = 8    # RGB padded to 8 channels so every implicit-GEMM K chunk is a full 16-byte vector
 
@@ -234,13 +234,22 @@ class MultimodalSC:
         """image: fp32 NCHW [B,3,H,W] in [0,1] -> tokens [B,(H/32)*(W/32),512]"""
         rt, P = self.rt, self.params
         B, C, H, W = image.shape
-        x = rt.empty(B, H, W, IMG_CPAD)
-        rt.call("msc_image_to_nhwc", image, x, B, C, H, W, IMG_CPAD, rt.dt)
-        if F._FUSED_STEM:
+        if F._FUSED_STEM and F._STEM_S2D and C == 3 and H % 2 == 0 and W % 2 == 0:
+            # the image re-blocked 2x2 -> 12 (16) channels: the 7x7/2 stem convolution as a 4x4/1 one (K 392 -> 256), then
+            # BN + ReLU + max-pool in one pass
+            x = rt.empty(B, H // 2, W // 2, 16)
+            rt.call("msc_image_to_s2d", image, x, B, H, W, rt.dt)
+            x = F.StemFn.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
+                               P["image_encoder.bn1.bias"], 2, 3, 3, 2, 1, P.stem_w)
+        elif F._FUSED_STEM:
+            x = rt.empty(B, H, W, IMG_CPAD)
+            rt.call("msc_image_to_nhwc", image, x, B, C, H, W, IMG_CPAD, rt.dt)
             # conv -> BN -> ReLU -> max-pool with the BN/ReLU/pool part in one pass (the post-activation map is never written)
             x = F.StemFn.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
                                P["image_encoder.bn1.bias"], 2, 3, 3, 2, 1)
         else:
+            x = rt.empty(B, H, W, IMG_CPAD)
+            rt.call("msc_image_to_nhwc", image, x, B, C, H, W, IMG_CPAD, rt.dt)
             x = F.ConvBNAct.apply(x, self.anchor, rt, P["image_encoder.conv1.weight"], P["image_encoder.bn1.weight"],
                                   P["image_encoder.bn1.bias"], 2, 3, True, False)
             x = F.MaxPool.apply(x, rt, 3, 2, 1)

@@ -259,6 +259,9 @@ class ParamStore:
             r.g = self.G[sl].view(r.shape)
             r.c = self.C[sl].view(r.shape)
             r.t = self.TR[sl] if r.kind in ("conv", "linear") else None
+        # ImageEncoder stem weights in the space-to-depth layout [Cout][4][4][16] (compute dtype), refreshed with the other compute copies
+        self.stem = self.refs.get("image_encoder.conv1.weight")
+        self.stem_w = torch.zeros(self.stem.shape[0] * 256, dtype=rt.tdtype, device=dev) if self.stem is not None else None
         self.step_count = 0
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # device-side step counter (hipGraph replay)
         self._ptable = None
@@ -298,6 +301,11 @@ class ParamStore:
             rt.call("msc_cast", self.P, self.C, self.total, rt.dt)
         t, blk = self._tables(self._ptable_split)["all"]
         rt.call("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
+        self._refresh_stem()
+
+    def _refresh_stem(self):
+        if self.stem is not None:
+            self.rt.call("msc_stem_weight_s2d", self.stem.p, self.stem_w, self.stem.shape[0], self.rt.dt)
 
     def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, overlap_from=None):
         """Fused Adam (+ bf16 shadow) over the flat buffers, then the transposed compute copies.
@@ -325,6 +333,7 @@ class ParamStore:
         t, blk = tabs["lo"]
         if t is not None:
             rt.call("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
+        self._refresh_stem()
         n_hi = self.total - split
         rt.call_side("msc_adam_step", self.P[split:], self.G[split:], self.M[split:], self.V[split:], shadow(split, self.total), n_hi, *hp)
         t, blk = tabs["hi"]

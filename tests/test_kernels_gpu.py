@@ -273,6 +273,60 @@ def test_persistent_conv_fwd_dgrad(rts, monkeypatch, tile, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H", [(2, 32), (3, 20), (1, 224)])
+def test_stem_space_to_depth(rts, dtype, B, H):
+    """The stem convolution (7x7 / stride 2 / pad 3 over RGB) in space-to-depth form against torch.nn.functional.conv2d and its
+    autograd weight gradient: re-blocking kernels exact (values are only moved), forward and weight gradient within the
+    per-kernel tolerances, BatchNorm partial sums consistent with the output."""
+    from multimodal_sc_amd import lib as L
+    rt = rts[dtype]
+    Cout = 64
+    img = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(1))
+    w = rnd(Cout, 7, 7, 3, seed=2, scale=0.1)
+    w8 = torch.zeros(Cout, 7, 7, 8)
+    w8[..., :3] = w
+    Hs = H // 2
+    xs = torch.full((B, Hs, Hs, 16), float("nan"), device=rt.device, dtype=rt.tdtype)
+    rt.call("msc_image_to_s2d", img.to(rt.device), xs, B, H, H, rt.dt)
+    want = img.view(B, 3, Hs, 2, Hs, 2).permute(0, 2, 4, 3, 5, 1).reshape(B, Hs, Hs, 12)       # [b][i][j][(dy,dx,c)]
+    torch.cuda.synchronize()
+    assert torch.equal(xs[..., :12].float().cpu(), q(want, dtype)) and (xs[..., 12:] == 0).all()
+    ws2d = torch.full((Cout, 4, 4, 16), float("nan"), device=rt.device, dtype=rt.tdtype)
+    rt.call("msc_stem_weight_s2d", w8.to(rt.device), ws2d, Cout, rt.dt)
+    torch.cuda.synchronize()
+    wr = ws2d.float().cpu().view(Cout, 4, 4, 16)
+    for kh in range(7):
+        for kw in range(7):
+            i, dy, j, dx = (kh + 1) >> 1, (kh + 1) & 1, (kw + 1) >> 1, (kw + 1) & 1
+            assert torch.equal(wr[:, i, j, (dy * 2 + dx) * 3:(dy * 2 + dx) * 3 + 3], q(w[:, kh, kw], dtype))
+    assert wr[..., 12:].abs().sum() == 0 and wr[:, 0, :, :6].abs().sum() == 0 and wr[:, :, 0, [0, 1, 2, 6, 7, 8]].abs().sum() == 0
+    # forward
+    iq, wq = q(img, dtype), q(w, dtype).requires_grad_()
+    ref = TF.conv2d(iq, wq.permute(0, 3, 1, 2), None, 2, 3)
+    M = B * Hs * Hs
+    nrows = L.query("msc_conv2d_fwd_stat_rows", M, Cout, rt.dt)
+    part = torch.full((nrows, 2, Cout), float("nan"), device=rt.device)
+    y = torch.full((B, Hs, Hs, Cout), float("nan"), device=rt.device, dtype=rt.tdtype)
+    rt.call("msc_stem_s2d_conv_fwd", xs, ws2d, y, part, B, Hs, Hs, Cout, rt.dt)
+    check("y", y, ref.permute(0, 2, 3, 1), tol(dtype))
+    check("sum", part[:, 0].sum(0), ref.sum((0, 2, 3)), 2e-3 * math.sqrt(M))
+    check("sumsq", part[:, 1].sum(0), ref.pow(2).sum((0, 2, 3)), 2e-3 * math.sqrt(M))
+    # weight gradient, back in the OHWI layout (padded channels exactly zero)
+    dy = rnd(B, Hs, Hs, Cout, seed=5)
+    ref.backward(q(dy, dtype).permute(0, 3, 1, 2))
+    wsb = L.query("msc_wgrad_workspace_bytes", Cout, 256, M)
+    wsw = torch.empty(max(wsb // 4, 1), device=rt.device)
+    dws = torch.full((Cout * 256,), float("nan"), device=rt.device)
+    rt.call("msc_stem_s2d_conv_wgrad", xs, dev(dy, rt), dws, wsw, wsb, B, Hs, Hs, Cout, 0, rt.dt)
+    g = torch.full((Cout, 7, 7, 8), 5.0, device=rt.device)
+    rt.call("msc_stem_wgrad_unpack", dws, g, Cout, 0)
+    check("dw", g[..., :3], wq.grad, tol(dtype, True) * 8)
+    assert (g[..., 3:] == 0).all()
+    rt.call("msc_stem_wgrad_unpack", dws, g, Cout, 1)                 # accumulate: doubles
+    check("dw x2", g[..., :3], 2 * wq.grad, tol(dtype, True) * 16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 14, 14, 64, 64, 3, 1, 1), (3, 7, 7, 256, 512, 3, 1, 1), (2, 14, 14, 64, 128, 3, 2, 1), (2, 14, 14, 64, 128, 1, 2, 0)])
 def test_conv_dgrad_relu_ref(rts, dtype, case):
     """msc_conv2d_dgrad with relu_ref: dx = (conv-transpose(dy) + res) * [relu_ref > 0], bit-identical to masking the plain result

@@ -3,6 +3,7 @@
 main stream when landmark kernels are enqueued (encoders fwd | fusion fwd | codec+heads fwd+loss | codec+heads bwd |
 fusion bwd | encoder bwd + optimizer), median over steps."""
 import os, sys, statistics
+os.environ.setdefault("MSC_REPLAY", "0")     # hooks the eager Python loop (a replayed step bypasses lib.call)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodal_sc_amd.model import MultimodalSC, named_config

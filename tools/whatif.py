@@ -4,6 +4,7 @@ this only answers "how much of the step does that work cost as scheduled", i.e. 
 Usage: whatif.py [regex ...]     e.g.  whatif.py 'wgrad'  'msc_bn_bwd|msc_bn_apply'  'msc_pillar'
 Prints ms/step (median of 3 x 30 steps) for the baseline and for each regex, all in one process on one box."""
 import os, re, sys, statistics, time
+os.environ.setdefault("MSC_REPLAY", "0")     # these tools hook the eager Python loop (a replayed step bypasses lib.call)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodal_sc_amd.model import MultimodalSC, named_config
