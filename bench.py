@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
-PMC_HBM_SUMMARY = "profiles/r2_pmc_hbm_bench_c3.csv"
+PMC_HBM_SUMMARY = "profiles/r3_pmc_hbm_bench_c3.csv"
 
 
 def gemm_source_sha():
@@ -207,6 +207,54 @@ def host_inputs_leg(args, cfg, model, trainer, dev_batch, ms_device_resident):
             "source": f"host memory ring of {nb} batches: uint8 camera frames + fp32 clouds + ego state"}
 
 
+def instrumented_pass(model, trainer, batch, torch):
+    """ONE stream (no side stream — Runtime.call_side falls back while rt.profile is set — and no BEV-branch stream), HIP events on
+    that stream around every C-ABI call: each kernel is timed running alone.  -> (per-call breakdown, gemm ms, flops, bytes, launches)"""
+    rt = model.rt
+    torch.cuda.synchronize()
+    rt.join_side()
+    rt.profile = []
+    branch = rt.branch_streams
+    rt.branch_streams = False
+    try:
+        trainer.forward_backward(batch)          # no collective here: only rank 0 runs the instrumented pass
+        model.params.adam_step(lr=1e-4)
+        torch.cuda.synchronize()
+    finally:
+        rt.branch_streams = branch
+    by = {}
+    gemm_t = gemm_f = gemm_b = 0.0
+    n_gemm = 0
+    for name, s, e0, e1 in rt.profile:
+        ms = e0.elapsed_time(e1)
+        d = by.setdefault(name, [0, 0.0])
+        d[0] += 1
+        d[1] += ms
+        f = gemm_flops(name, s)
+        if f is not None:
+            gemm_t += ms
+            gemm_f += f
+            gemm_b += gemm_bytes(name, s)
+            n_gemm += 1
+    rt.profile = None
+    return by, gemm_t, gemm_f, gemm_b, n_gemm
+
+
+def instrumented_only(args, model, trainer, batch):
+    import torch
+    instrumented_pass(model, trainer, batch, torch)          # warm-up (workspaces, code objects)
+    ts = []
+    for _ in range(args.instrumented_only):
+        _, gemm_t, gemm_f, _, n_gemm = instrumented_pass(model, trainer, batch, torch)
+        ts.append(gemm_t)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    print(json.dumps({"mode": "instrumented-only", "passes": len(ts), "kernel": "gemm_kernel<bf16,*> family (C-ABI GEMM calls incl. their split-K helpers)",
+                      "kernel_ms_per_pass_median": med, "kernel_ms_per_pass_all": ts, "launches_per_pass": n_gemm,
+                      "algorithmic_gflop_per_pass": gemm_f / 1e9, "achieved_tflops": gemm_f / (med * 1e-3) / 1e12}))
+    return 0
+
+
 def allreduce_probe(model, trainer, dist, torch, reps=5):
     """N>1, outside the timed region: each piece of the gradient exchange alone (barrier, `reps` all-reduces, max over
     ranks) -> ms and algorithmic GB/s per rank, so a scaling run explains itself."""
@@ -289,6 +337,9 @@ def main(argv=None):
     ap.add_argument("--host-inputs", action="store_true",
                     help="also time the step fed from a host-resident frame source (pinned ring + H2D staging)")
     ap.add_argument("--selftest-ranks", action="store_true", help="launch-path self-test on gloo: no GPU, no model")
+    ap.add_argument("--instrumented-only", type=int, default=0, metavar="N",
+                    help="profiling aid: run ONLY N single-stream instrumented passes (every kernel alone, HIP events around it) — "
+                         "`rocprofv3 --kernel-trace --stats` of this command is the summary roofline.achieved must agree with")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -334,6 +385,9 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.instrumented_only:
+        return instrumented_only(args, model, trainer, batch)
+
     for _ in range(args.warmup):
         trainer.step(batch)
     barrier()
@@ -375,33 +429,9 @@ def main(argv=None):
         result["host_inputs"] = host_inputs_leg(args, cfg, model, trainer, batch, result["ms_per_step"])
 
     if rank == 0 and not args.no_roofline:
-        rt = model.rt
-        torch.cuda.synchronize()
-        rt.join_side()
-        # instrumented pass: ONE stream (no side stream — Runtime.call_side falls back while rt.profile is set — and no
-        # BEV-branch stream), HIP events on that stream around every C-ABI call: each kernel is timed running alone
-        rt.profile = []
-        branch = rt.branch_streams
-        rt.branch_streams = False
-        trainer.forward_backward(batch)          # no collective here: only rank 0 runs the instrumented pass
-        model.params.adam_step(lr=1e-4)
-        torch.cuda.synchronize()
-        rt.branch_streams = branch
-        by = {}
-        gemm_t = gemm_f = gemm_b = 0.0
-        n_gemm = 0
-        for name, s, e0, e1 in rt.profile:
-            ms = e0.elapsed_time(e1)
-            d = by.setdefault(name, [0, 0.0])
-            d[0] += 1
-            d[1] += ms
-            f = gemm_flops(name, s)
-            if f is not None:
-                gemm_t += ms
-                gemm_f += f
-                gemm_b += gemm_bytes(name, s)
-                n_gemm += 1
-        rt.profile = None
+        # instrumented pass: every kernel alone on one stream, HIP events on that stream around every C-ABI call (see instrumented_pass);
+        # profiles/r3_kernel_stats_instrumented.csv is `rocprofv3 --kernel-trace --stats` of `bench.py --instrumented-only 8`
+        by, gemm_t, gemm_f, gemm_b, n_gemm = instrumented_pass(model, trainer, batch, torch)
         achieved = gemm_f / (gemm_t * 1e-3) / 1e12
         traffic, traffic_src = pmc_hbm_bytes_per_gemm_launch(n_gemm)
         result["build_id"] = __import__("multimodal_sc_amd.lib", fromlist=["lib"]).lib.msc_build_id().decode()
