@@ -443,7 +443,11 @@ def main(argv=None):
                               # the same FLOPs over the WHOLE timed step (checkable against the driver's clock around the run):
                               # what the step sees, with every other kernel, the stream overlap and the host loop included
                               "whole_step_tflops": gemm_f / (result["ms_per_step"] * 1e-3) / 1e12,
-                              "whole_step_frac": gemm_f / (result["ms_per_step"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+                              "whole_step_frac": gemm_f / (result["ms_per_step"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                              # how this figure relates to the committed rocprofv3 summary of the same single-stream pass
+                              "rocprof_stats": "profiles/r3_kernel_stats_instrumented.csv = rocprofv3 --kernel-trace --stats of `bench.py --instrumented-only 8`; "
+                                               "profiles/r3_stats_vs_bench.txt: the event brackets read ~12 % longer than the kernel durations they enclose "
+                                               "(marker + dispatch latency of ~5 us per C-ABI call), so `achieved` is the conservative of the two"}
         result["breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
