@@ -133,7 +133,8 @@ int msc_gemm_batched(const void* A, const void* Bm, void* C, int M, int N, int K
  * FusionTransformer: fused (flash-style) multi-head attention, head_dim 64, bf16 (MSC_ERR_UNSUPPORTED otherwise —
  * the exact-fp32 parity mode uses msc_gemm_batched + msc_softmax_*).  qkv: [B*T][3*H*64] (q | k | v, heads inside),
  * o: [B*T][H*64], lse: fp32 [B*H][msc_attention_tpad(T)] (log2-domain log-sum-exp, saved for the backward),
- * delta: fp32 scratch of the same shape, dqkv: [B*T][3*H*64].  No score matrix is written to HBM. */
+ * delta: fp32 scratch [2][B*H][msc_attention_tpad(T)] (the dQ pass leaves the row constants of the dK/dV pass there: -rowsum(dO*O)
+ * and -lse/c, the initial values of that pass's accumulators), dqkv: [B*T][3*H*64].  No score matrix is written to HBM. */
 int64_t msc_attention_tpad(int T);
 int msc_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int hd, float scale, int dtype,
                       void* stream);

@@ -27,6 +27,9 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #ifndef ATT_ABLATE
 #define ATT_ABLATE 0
 #endif
+#ifndef ATT_BWD_OCC
+#define ATT_BWD_OCC 2      // waves per SIMD the backward kernels are compiled for (3 = 168 VGPRs spills both: 9 / 65 registers)
+#endif
 
 // Chunk swizzle of a 128-B-row image that is read BOTH by rows (ds_read_b128: the 8 even and 8 odd rows of a 16-lane
 // group must spread one chunk index over 8 distinct values -> a bijection of t = (row>>1)&7) AND transposed
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
 // ================================================================================================ backward: dQ (+ delta)
 // wave w owns query tiles w, w+nwaves, ...; K and V panels resident in LDS.  (One wave per tile was tried: at ~190 VGPRs
 // per wave the extra waves only fit by spilling, and the kernel got slower.)
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, bf16_t* __restrict__ dqkv, int T, int Tpad,
                                                            int H, float c_log2, float scale) {
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int NT = Tpad >> 5;
+  const long stat2 = (long)gridDim.x * Tpad;      // second half of the statistics scratch: -lse / c
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)0x7ffffff0, 0x00020000);
   const uint32_t row0 = (uint32_t)b * (uint32_t)T * (uint32_t)ld;
   if (ATT_ABLATE != 11) {
@@ -251,7 +255,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
     }
     dl += __shfl_xor(dl, 32, 64);                       // delta[q] = sum_d dO*O
     const float ls = qv ? lse[(long)bh * Tpad + qrow] : INFINITY;   // padded query rows: P = 0
-    if (qv && lh == 0) delta[(long)bh * Tpad + qrow] = dl;
+    if (qv && lh == 0) {      // row constants of the dK/dV pass, stored the way that pass consumes them (accumulator initial values)
+      delta[(long)bh * Tpad + qrow] = -dl;
+      delta[stat2 + (long)bh * Tpad + qrow] = -ls / c_log2;
+    }
     f32x16_t dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
 
 // ================================================================================================ backward: dK, dV
 // wave w owns key tiles w, w+nwaves, ...; Q and dO panels resident in LDS (rows + transposed reads).
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int T, int Tpad, int H, float c_log2, float scale) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -311,8 +318,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const float* lse_b = lse + (long)bh * Tpad;
-  const float* del_b = delta + (long)bh * Tpad;
+  // row constants as the dQ pass left them: -delta and -lse / c.  They are the INITIAL VALUES of the dP and S accumulators
+  // (S' = Q K^T - lse / c, so p = exp2(c S') needs no subtraction; dP' = dO V^T - delta, so dS = p dP'): 16-byte loads straight into
+  // the accumulator registers, no registers of their own (the version that prefetched them a tile ahead needed 32 more and spilled)
+  const float* nls_b = delta + (long)gridDim.x * Tpad + (long)bh * Tpad;
+  const float* ndl_b = delta + (long)bh * Tpad;
+  (void)lse;
 
   for (int kt = wave; kt < NT; kt += nwaves) {
     const int krow = kt * 32 + lr;
@@ -329,50 +340,44 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    // registers 4g..4g+3 of an S tile hold query rows qt*32 + 8g + 4lh + {0,1,2,3}: one 16-byte load each of lse and
-    // delta per g.  They come from HBM/L2, so the loads for tile qt+1 are issued before the products of tile qt
-    // (software prefetch, 32 VGPRs, issued right after the current tile's statistics were consumed): with two waves per SIMD nothing else would hide their latency.
-    float4 lnx[4], dnx[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      lnx[g] = *reinterpret_cast<const float4*>(lse_b + 8 * g + 4 * lh);
-      dnx[g] = *reinterpret_cast<const float4*>(del_b + 8 * g + 4 * lh);
-    }
+    // The 32 row constants of a query tile travel ONE PER LANE (lane l and l+32 hold row l & 31): two 4-byte loads per tile, issued a
+    // whole tile ahead (2 registers, where 16-byte-per-register loads needed 32), and are spread into the accumulator layout — register
+    // r of lane half lh is row (r & 3) + 8 (r >> 2) + 4 lh — by ds_bpermute (wavefront shuffle, no LDS storage).  Rows >= T get
+    // -inf / 0 at the load: P = 0, dP' finite (their dO rows were staged as zeros), so the ragged tail needs no mask in the loop.
+    auto stat_load = [&](int qt, float& a, float& bq) {
+      const int q = qt * 32 + lr;
+      const bool v = qt < NT && q < T;
+      a = v ? nls_b[q] : -INFINITY;
+      bq = v ? ndl_b[q] : 0.f;
+    };
+    float nls_c, ndl_c, nls_n, ndl_n;
+    stat_load(0, nls_c, ndl_c);
+    const int shb = 4 * lh;
     for (int qt = 0; qt < NT; ++qt) {
+      stat_load(qt + 1, nls_n, ndl_n);
       f32x16_t s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) {
+        const int src = (r & 3) + 8 * (r >> 2) + shb;
+        s[r] = __shfl(nls_c, src, 64);
+        dp[r] = __shfl(ndl_c, src, 64);
+      }
+      nls_c = nls_n;
+      ndl_c = ndl_n;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ATT_ABLATE == 14) break;
-        s = MFMA(frag_rows(Qimg, qt * 32 + lr, 2 * ks + lh), kf[ks], s);     // S[q][key]
-        dp = MFMA(frag_rows(Gimg, qt * 32 + lr, 2 * ks + lh), vf[ks], dp);   // dP[q][key]
+        s = MFMA(frag_rows(Qimg, qt * 32 + lr, 2 * ks + lh), kf[ks], s);     // S'[q][key] = S - lse / c
+        dp = MFMA(frag_rows(Gimg, qt * 32 + lr, 2 * ks + lh), vf[ks], dp);   // dP'[q][key] = dP - delta
       }
-      f32x16_t ds;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int q0 = qt * 32 + 8 * g + 4 * lh;
-        const float4 l4 = lnx[g];
-        const float4 d4 = dnx[g];
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const bool ok = kvld && (q0 + e < T);   // padded rows of lse/delta hold garbage: never let it reach the math
-          if (ATT_ABLATE == 12) { ds[r] = s[r] + dp[r] + lv[e] + dvv[e]; continue; }
-          const float p = ok ? __builtin_amdgcn_exp2f(s[r] * c_log2 - lv[e]) : 0.f;
-          s[r] = p;
-          ds[r] = ok ? p * (dp[r] - dvv[e]) : 0.f;
-        }
+      for (int r = 0; r < 16; ++r) {
+        if (ATT_ABLATE == 12) { dp[r] += s[r]; continue; }
+        const float p = __builtin_amdgcn_exp2f(s[r] * c_log2);
+        s[r] = p;
+        dp[r] = p * dp[r];                                                    // dS, in place (padded KEYS are never stored)
       }
-      if (qt + 1 < NT) {   // next tile's statistics: in flight under the four products below and the next tile's S / dP
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          lnx[g] = *reinterpret_cast<const float4*>(lse_b + (qt + 1) * 32 + 8 * g + 4 * lh);
-          dnx[g] = *reinterpret_cast<const float4*>(del_b + (qt + 1) * 32 + 8 * g + 4 * lh);
-        }
-      }
-      const bfx8 p0 = pack8(s, 0), p1 = pack8(s, 1), e0 = pack8(ds, 0), e1 = pack8(ds, 1);
+      const bfx8 p0 = pack8(s, 0), p1 = pack8(s, 1), e0 = pack8(dp, 0), e1 = pack8(dp, 1);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         if (ATT_ABLATE == 13) { dv[dt][0] += (float)p0[0] + (float)p1[0]; dk[dt][0] += (float)e0[0] + (float)e1[0]; continue; }
@@ -405,9 +410,9 @@ extern "C" int msc_attention_fwd(const void* qkv, void* o, float* lse, int B, in
   const size_t lds = (size_t)2 * Tpad * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(64 * nw), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse, T, Tpad, H,
@@ -415,7 +420,7 @@ extern "C" int msc_attention_fwd(const void* qkv, void* o, float* lse, int B, in
   return msc_launch_status();
 }
 
-// lse: from the forward; delta: fp32 scratch [B*H][Tpad] (written by the dQ kernel, read by the dK/dV kernel)
+// lse: from the forward; delta: fp32 scratch [2][B*H][Tpad] (written by the dQ kernel, read by the dK/dV kernel)
 extern "C" int msc_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int T,
                                  int H, int hd, float scale, int dtype, void* stream) {
   MSC_CHECK_ARG(qkv && o && dout && lse && delta && dqkv && B > 0 && T > 0 && H > 0 && scale > 0.f);

@@ -489,7 +489,7 @@ def attention_bwd(rt: Runtime, do, qkv, o, P, B, T, h, hd):
     if fused_attention_ok(rt, T, hd):
         lse = P
         dqkv = rt.empty(B * T, 3 * D)
-        delta = rt.workspace("attn_delta", lse.numel() * 4)
+        delta = rt.workspace("attn_delta", 2 * lse.numel() * 4)       # [2][B*h][Tpad]: -delta and -lse/c (see msc.h)
         rt.call("msc_attention_bwd", qkv, o, do, lse, delta, dqkv, B, T, h, hd, 1.0 / math.sqrt(hd), rt.dt)
         return dqkv
     Tp = P.shape[-1]
@@ -603,7 +603,7 @@ def _fusion_bwd_two_chains(ctx, dy):
     dx2 = dy.reshape(M, D).contiguous()
     dpre, dh2, dx1, do = rt.empty(M, Fh), rt.empty(M, D), rt.empty(M, D), rt.empty(M, D)
     dqkv, dh1, dx = rt.empty(M, 3 * D), rt.empty(M, D), rt.empty(M, D)
-    delta = rt.f32(*lse.shape)
+    delta = rt.f32(2 * lse.numel())                              # per chain [2][frames*h][Tpad]: -delta | -lse/c
     Tpad = lse.shape[1]
     # per-row-block partials of the LayerNorm parameter gradients: [ln1 | ln2][chain] buffers, reduced on the side stream
     lnp = [[rt.f32(L.query("msc_layernorm_bwd_workspace_bytes", n, D) // 4) for n in ((B // 2) * T, (B - B // 2) * T)] for _ in range(2)]
@@ -649,7 +649,7 @@ def _fusion_bwd_two_chains(ctx, dy):
         for c, r0, n, _, _, _ in chains:
             call("msc_linear_dgrad", a_dx1 + r0 * rD, tp, None, None, L.ACT_NONE, None, a_do + r0 * rD, n, D, D, dt, c)
         for c, r0, n, l0, nb, _ in chains:
-            call("msc_attention_bwd", a_qkv + r0 * r3D, a_o + r0 * rD, a_do + r0 * rD, a_lse + l0 * Tpad * 4, a_delta + l0 * Tpad * 4,
+            call("msc_attention_bwd", a_qkv + r0 * r3D, a_o + r0 * rD, a_do + r0 * rD, a_lse + l0 * Tpad * 4, a_delta + 2 * l0 * Tpad * 4,
                  a_dqkv + r0 * r3D, nb, T, h, hd, scale, dt, c)
         wgrad(h1, dqkv, p["qkvw"], p["qkvb"])
         for c, r0, n, _, _, _ in chains:

@@ -11,7 +11,8 @@ NAMES = {0: "baseline", 1: "fwd: no K/V staging", 2: "fwd: no softmax", 3: "fwd:
 
 def build():
     os.makedirs(ABL, exist_ok=True)
-    others = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".o") and f != "attention.o"]
+    # the product's objects only (one per .hip source): alternative builds (make alt / stamp) leave extra objects beside them
+    others = [os.path.join(CSRC, f[:-4] + ".o") for f in os.listdir(CSRC) if f.endswith(".hip") and f != "attention.hip"]
     procs = []
     for n in NAMES:
         obj = os.path.join(ABL, f"attn_abl{n}.o")
@@ -37,7 +38,7 @@ def child(n):
     Tp = L.query("msc_attention_tpad", T)
     lse = torch.empty(B * H * Tp, device=rt.device)
     do = (torch.randn(B * T, D, device=rt.device) * 0.5).to(torch.bfloat16)
-    dqkv, delta = torch.empty_like(qkv), torch.empty_like(lse)
+    dqkv, delta = torch.empty_like(qkv), torch.empty(2 * lse.numel(), device=rt.device)
     rt.call("msc_attention_fwd", qkv, o, lse, B, T, H, 64, 0.125, rt.dt)
     if n >= 10:
         fn = lambda: rt.call("msc_attention_bwd", qkv, o, do, lse, delta, dqkv, B, T, H, 64, 0.125, rt.dt)

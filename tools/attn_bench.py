@@ -10,7 +10,7 @@ o = torch.empty(B * T, D, device=rt.device, dtype=torch.bfloat16)
 do = (torch.randn(B * T, D, device=rt.device) * 0.5).to(torch.bfloat16)
 dqkv = torch.empty_like(qkv)
 Tp = L.query("msc_attention_tpad", T)
-lse = torch.empty(B * H * Tp, device=rt.device); delta = torch.empty_like(lse)
+lse = torch.empty(B * H * Tp, device=rt.device); delta = torch.empty(2 * lse.numel(), device=rt.device)
 def t(fn, n=50):
     for _ in range(3): fn()
     torch.cuda.synchronize()
