@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
@@ -40,8 +41,25 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
                            // Measured (profiles/r3_attn_ablate.txt): correct, but 116-117 us per layer against 111 — the extra fragment
                            // reads and 256 VGPRs cost more than the overlap of the two MFMA stages returns.  Not in the product build.
 #endif
+#ifndef ATT_DKV_PIPE
+#define ATT_DKV_PIPE 0     // 1 (experiment build): the two-accumulator-set software pipeline of the loop over the query tiles with K / V in registers
+#endif
 #ifndef ATT_BWD_OCC
 #define ATT_BWD_OCC 2      // waves per SIMD the backward kernels are compiled for (3 = 168 VGPRs spills both: 9 / 65 registers)
+#endif
+
+// ATT_STAMP: diagnostic build only (make alt ALT=attstamp ALT_SRC=attention ALT_FLAGS=-DATT_STAMP; tools/attn_stamps.py).  Wave 0 of every
+// workgroup of the dK/dV pass sums shader-clock cycles per loop segment into a debug buffer of its own that nothing else reads:
+// [0] statistics shuffle + S'/dP' (LDS row reads + 8 MFMAs, until their results can be read), [1] exponentials / dS / bf16 packing,
+// [2] dV / dK (16 transposed LDS reads + 8 MFMAs, until results readable), [3] whole loop of the wave's first key tile, [4] prologue
+// (staging), [5] iterations, [6] / [7] clock at kernel entry / after the wave's last store.
+#ifdef ATT_STAMP
+__device__ unsigned long long g_att_stamps[4096 * 8];
+extern "C" int msc_debug_attn_stamps(unsigned long long* host_out, int nwg) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_att_stamps), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
+#define ATT_T(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATT_TOUCH(x) do { float t_; asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"(x)); asm volatile("" :: "v"(t_)); } while (0)
 #endif
 
 // Chunk swizzle of a 128-B-row image that is read BOTH by rows (ds_read_b128: the 8 even and 8 odd rows of a 16-lane
@@ -331,6 +349,10 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
   const int NT = Tpad >> 5;
   __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)0x7ffffff0, 0x00020000);
   __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, (int)0x7ffffff0, 0x00020000);
+#ifdef ATT_STAMP
+  unsigned long long tp0, tp1;
+  ATT_T(tp0);
+#endif
   if (ATT_ABLATE != 11) {
     stage_image<true>(Qimg, rsq, (uint32_t)b * (uint32_t)T * (uint32_t)ld + h * ATT_HD, ld, T, Tpad, nwaves);
     stage_image<true>(Gimg, rsg, (uint32_t)b * (uint32_t)T * (uint32_t)D + h * ATT_HD, D, T, Tpad, nwaves);
@@ -341,9 +363,11 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // row constants as the dQ pass left them: -delta and -lse / c.  They are the INITIAL VALUES of the dP and S accumulators
-  // (S' = Q K^T - lse / c, so p = exp2(c S') needs no subtraction; dP' = dO V^T - delta, so dS = p dP'): 16-byte loads straight into
-  // the accumulator registers, no registers of their own (the version that prefetched them a tile ahead needed 32 more and spilled)
+#ifdef ATT_STAMP
+  ATT_T(tp1);
+#endif
+  // row constants as the dQ pass left them: -delta and -lse / c.  S' = Q K^T - lse / c (so p = exp2(c S')) and dP' = dO V^T - delta
+  // (so dS = p dP'): the constants enter the products as ONE MORE K-STEP of the MFMA chain (see aug() below)
   const float* nls_b = delta + (long)gridDim.x * Tpad + (long)bh * Tpad;
   const float* ndl_b = delta + (long)bh * Tpad;
   (void)lse;
@@ -366,24 +390,35 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
     // The 32 row constants of a query tile travel ONE PER LANE (lane l and l+32 hold row l & 31): two 4-byte loads per tile, issued a
-    // whole tile ahead (2 registers, where 16-byte-per-register loads needed 32), and are spread into the accumulator layout — register
-    // r of lane half lh is row (r & 3) + 8 (r >> 2) + 4 lh — by ds_bpermute (wavefront shuffle, no LDS storage).  Rows >= T get
-    // -inf / 0 at the load: P = 0, dP' finite (their dO rows were staged as zeros), so the ragged tail needs no mask in the loop.
+    // whole tile ahead.  A row constant is a per-ROW bias of a 32x32 product whose rows are this operand's rows: it is the product of
+    // one extra k-step whose A fragment holds the constant — split into three bf16 terms (hi + mid + lo = 24 significant bits, every
+    // product with 1.0 exact, summed in the fp32 accumulator) in k slots 0..2 of lane half 0, zeros elsewhere — and whose B fragment
+    // is all ones.  Two more MFMAs per tile (16 -> 18) replace 32 ds_bpermute (the LDS pipe of the CU is the contended unit of this
+    // loop: 8 waves x 16 KB of fragment reads per tile) + 32 VALU adds, and they depend on nothing the LDS reads deliver: the chain
+    // starts while the row fragments are still in flight.  Rows >= T get -1e30 / 0 at the load: P = exp2(-huge) = 0, dP' finite
+    // (their dO rows were staged as zeros), so the ragged tail needs no mask in the loop.
     auto stat_load = [&](int qt, float& a, float& bq) {
       const int q = qt * 32 + lr;
       const bool v = qt < NT && q < T;
-      a = v ? nls_b[q] : -INFINITY;
+      a = v ? nls_b[q] : -1e30f;
       bq = v ? ndl_b[q] : 0.f;
     };
-    const int shb = 4 * lh;
-    // stage 1 of tile qt: accumulators start from the row constants (spread from the one-per-lane registers), then S' and dP'
+    auto aug = [&](float x) -> bfx8 {
+      const bf16_t h1 = f32_to_bf16(x);
+      const float r1 = x - bf16_to_f32(h1);
+      const bf16_t h2 = f32_to_bf16(r1);
+      const bf16_t h3 = f32_to_bf16(r1 - bf16_to_f32(h2));
+      u32x4 w = {lh ? 0u : ((uint32_t)h1 | ((uint32_t)h2 << 16)), lh ? 0u : (uint32_t)h3, 0u, 0u};
+      return __builtin_bit_cast(bfx8, w);
+    };
+    const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bfx8 ones = __builtin_bit_cast(bfx8, ones_w);
+    // stage 1 of tile qt: S' and dP' (row-constant k-step first, then the four k-steps over the head dimension)
     auto stage1 = [&](int qt, float nls, float ndl, f32x16_t& s, f32x16_t& dp) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int src = (r & 3) + 8 * (r >> 2) + shb;
-        s[r] = __shfl(nls, src, 64);
-        dp[r] = __shfl(ndl, src, 64);
-      }
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      s = MFMA(aug(nls), ones, s);
+      dp = MFMA(aug(ndl), ones, dp);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ATT_ABLATE == 14) break;
@@ -417,7 +452,7 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
         dk[dt] = MFMA(a1, e1, dk[dt]);
       }
     };
-    if constexpr (KVLDS) {
+    if constexpr (KVLDS || ATT_DKV_PIPE) {
     // Software pipeline over the query tiles, two named accumulator sets: the S' / dP' products of tile qt+1 are in program order BEFORE
     // the exponentials and the dV / dK products of tile qt, so the matrix pipe has independent work while the VALU finishes a tile
     // (with two waves per SIMD nothing else covers the LDS-read -> MFMA -> exp -> transposed-read -> MFMA chain of one tile).
@@ -443,20 +478,66 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
     } else {
     float nls_c, ndl_c, nls_n, ndl_n;
     stat_load(0, nls_c, ndl_c);
+#ifdef ATT_STAMP
+    unsigned long long a0, a1, a2, a3, seg0 = 0, seg1 = 0, seg2 = 0, tl0, tl1, iters = 0;
+    ATT_T(tl0);
+#endif
     for (int qt = 0; qt < NT; ++qt) {
       stat_load(qt + 1, nls_n, ndl_n);
       f32x16_t s, dp;
+#ifdef ATT_STAMP
+      ATT_T(a0);
+      stage1(qt, nls_c, ndl_c, s, dp);
+      ATT_TOUCH(s[15]); ATT_TOUCH(dp[15]);
+      ATT_T(a1);
+      nls_c = nls_n;
+      ndl_c = ndl_n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[r] * c_log2);
+        s[r] = p;
+        dp[r] = p * dp[r];
+      }
+      const bfx8 p0 = pack8(s, 0), p1 = pack8(s, 1), e0 = pack8(dp, 0), e1 = pack8(dp, 1);
+      asm volatile("" :: "v"(p0), "v"(p1), "v"(e0), "v"(e1));
+      ATT_T(a2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bfx8 g0 = frag_tr_perm<true>(Gimg, qt * 32, dt * 32), g1 = frag_tr_perm<true>(Gimg, qt * 32 + 16, dt * 32);
+        dv[dt] = MFMA(g0, p0, dv[dt]);
+        dv[dt] = MFMA(g1, p1, dv[dt]);
+        const bfx8 q0 = frag_tr_perm<true>(Qimg, qt * 32, dt * 32), q1 = frag_tr_perm<true>(Qimg, qt * 32 + 16, dt * 32);
+        dk[dt] = MFMA(q0, e0, dk[dt]);
+        dk[dt] = MFMA(q1, e1, dk[dt]);
+      }
+      ATT_TOUCH(dv[1][15]); ATT_TOUCH(dk[1][15]);
+      ATT_T(a3);
+      seg0 += a1 - a0; seg1 += a2 - a1; seg2 += a3 - a2; ++iters;
+#else
       stage1(qt, nls_c, ndl_c, s, dp);
       nls_c = nls_n;
       ndl_c = ndl_n;
       stage2(qt, s, dp);
+#endif
     }
+#ifdef ATT_STAMP
+    ATT_T(tl1);
+    if (threadIdx.x == 0 && kt == 0 && blockIdx.x < 4096) {
+      unsigned long long* o = g_att_stamps + (size_t)blockIdx.x * 8;
+      o[0] = seg0; o[1] = seg1; o[2] = seg2; o[3] = tl1 - tl0; o[4] = tp1 - tp0; o[5] = iters; o[6] = tp0;
+    }
+#endif
     }
     if (kvld) {
       store_rowT(dqkv + grow * ld + D + h * ATT_HD, dk, scale, lh);
       store_rowT(dqkv + grow * ld + 2 * D + h * ATT_HD, dv, 1.f, lh);
     }
   }
+#ifdef ATT_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_T(tp1);
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_att_stamps[(size_t)blockIdx.x * 8 + 7] = tp1;
+#endif
 }
 
 // ================================================================================================ C-ABI
@@ -501,7 +582,9 @@ extern "C" int msc_attention_bwd(const void* qkv, const void* o, const void* dou
   // <= 8 waves: the kernels need ~190-256 VGPRs (two waves per SIMD); 8 measured best inside the step (5: -0.5 %)
   const int nt = Tpad / 32;
   const int nwb = nwb_env > 0 ? (nwb_env > 8 ? 8 : nwb_env) : (nt < 8 ? nt : 8);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(64 * nwb), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
+  static int nwq_env = getenv("MSC_ATT_DQ_WAVES") ? atoi(getenv("MSC_ATT_DQ_WAVES")) : 0;
+  const int nwq = nwq_env > 0 ? (nwq_env > 8 ? 8 : nwq_env) : nwb;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(64 * nwq), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                      delta, (bf16_t*)dqkv, T, Tpad, H, c, scale);
 #if ATT_DKV_KVLDS
   static const int kvlds_env = getenv("MSC_ATT_DKV_KVLDS") ? atoi(getenv("MSC_ATT_DKV_KVLDS")) : 1;     // A/B knob of the experiment build
