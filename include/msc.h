@@ -29,7 +29,12 @@ extern "C" {
 
 enum { MSC_F32 = 0, MSC_BF16 = 1 };
 enum { MSC_OK = 0, MSC_ERR_BAD_ARG = -1, MSC_ERR_LAUNCH = -2, MSC_ERR_UNSUPPORTED = -3 };
-enum { MSC_ACT_NONE = 0, MSC_ACT_RELU = 1, MSC_ACT_GELU = 2, MSC_ACT_TANH = 3, MSC_ACT_SIGMOID = 4 };
+enum { MSC_ACT_NONE = 0, MSC_ACT_RELU = 1, MSC_ACT_GELU = 2, MSC_ACT_TANH = 3, MSC_ACT_SIGMOID = 4,
+       /* msc_linear_fwd only: y = gelu(u) and the side output `pre` receives gelu'(u) instead of u — the derivative shares the
+        * exponential of the erf evaluation, and the backward epilogue then multiplies instead of evaluating erf + exp per element */
+       MSC_ACT_GELU_DSAVE = 5,
+       /* msc_linear_dgrad's `dact` only: dact_ref holds the derivative itself (what MSC_ACT_GELU_DSAVE stored): dx *= dact_ref */
+       MSC_ACT_MUL_REF = 6 };
 enum { MSC_CH_AWGN = 0, MSC_CH_RAYLEIGH = 1 };
 
 const char* msc_strerror(int code);
@@ -98,15 +103,16 @@ int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_
 /* ---------------------------------------------------------------------------------------------
  * FusionTransformer / SemanticEncoder / SemanticDecoder / heads: dense layers.
  * y[M,N] = act(x[M,K] w[N,K]^T + bias[N]) + res[M,N];  pre (may be NULL) receives the
- * pre-activation (needed by GELU/tanh backward).  bias,res,pre optional.  bias is fp32. */
+ * pre-activation (needed by GELU/tanh backward; act = MSC_ACT_GELU_DSAVE: the derivative gelu'(pre-activation) instead).
+ * bias,res,pre optional.  bias is fp32. */
 int msc_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, void* pre,
                    int M, int N, int K, int act, int dtype, void* stream);
 /* dx[M,K] = (dy[M,N] wt[K,N]^T + res[M,K]) * act'(dact_ref[M,K])   (wt = w transposed, [K][N] row-major).
  * res (optional, T): a gradient w.r.t. this layer's input arriving over another branch (a tensor with two consumers), summed here
  * in fp32 before the one rounding of dx.
  * dact_ref/dact (optional): fused backward of the activation that FED this layer — dact_ref is that activation's
- * output (relu/tanh/sigmoid) or pre-activation (gelu); dx is then the gradient w.r.t. the previous layer's
- * pre-activation.  colsum_partial (optional): fp32 [msc_linear_dgrad_colsum_rows(M,K,dtype)][K] per-row-block column sums
+ * output (relu/tanh/sigmoid), pre-activation (gelu) or stored derivative (MSC_ACT_MUL_REF); dx is then the gradient w.r.t.
+ * the previous layer's pre-activation.  colsum_partial (optional): fp32 [msc_linear_dgrad_colsum_rows(M,K,dtype)][K] per-row-block column sums
  * of dx (= the previous layer's bias gradient after msc_colsum_finalize). */
 int64_t msc_linear_dgrad_colsum_rows(int64_t M, int K, int dtype);
 int msc_linear_dgrad(const void* dy, const void* wt, const void* res, const void* dact_ref, int dact, float* colsum_partial, void* dx,
@@ -210,7 +216,7 @@ int msc_tokens_split(const void* dout, void* d0, void* d1, void* d2, int B, int 
                      int dtype, void* stream);
 int msc_meanpool_fwd(const void* x, void* y, int B, int T, int D, int dtype, void* stream);
 int msc_meanpool_bwd(const void* dy, void* dx, int B, int T, int D, int dtype, void* stream);
-/* ref = output for relu/tanh/sigmoid, pre-activation for gelu */
+/* ref = output for relu/tanh/sigmoid, pre-activation for gelu, the derivative itself for MSC_ACT_MUL_REF */
 int msc_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, int dtype, void* stream);
 int msc_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
 

@@ -326,6 +326,7 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ r
         case MSC_ACT_TANH: d = 1.f - y * y; break;
         case MSC_ACT_SIGMOID: d = y * (1.f - y); break;
         case MSC_ACT_GELU: d = 0.5f * (1.f + fast_erf(y * 0.70710678118654752f)) + y * 0.3989422804014327f * __expf(-0.5f * y * y); break;
+        case MSC_ACT_MUL_REF: d = y; break;
         default: d = 1.f;
       }
       g.v[j] *= d;

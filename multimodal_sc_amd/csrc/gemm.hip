@@ -877,14 +877,20 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
             }
           }
           vecf<T> vo;
-          if (C2) {
+          if (p.act == MSC_ACT_GELU_DSAVE) {      // y = gelu(u), side output = gelu'(u)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) vo.v[e] = v[e];
-            if constexpr (GEMM_NT_STORE) vo.store_nt(C2 + o); else vo.store(C2 + o);
-          }
-          if (p.act != MSC_ACT_NONE) {
+            for (int e = 0; e < VEC; ++e) gelu_both(v[e], v[e], vo.v[e]);
+            if (C2) { if constexpr (GEMM_NT_STORE) vo.store_nt(C2 + o); else vo.store(C2 + o); }
+          } else {
+            if (C2) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = act_apply(v[e], p.act);
+              for (int e = 0; e < VEC; ++e) vo.v[e] = v[e];
+              if constexpr (GEMM_NT_STORE) vo.store_nt(C2 + o); else vo.store(C2 + o);
+            }
+            if (p.act != MSC_ACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) v[e] = act_apply(v[e], p.act);
+            }
           }
           if (Rs) {
             vecf<T> vr;
@@ -910,8 +916,14 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
         } else {
           for (int e = 0; e < VEC && n + e < p.N; ++e) {
             float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
-            if (C2) msc_traits<T>::st(C2 + o + e, x);
-            x = act_apply(x, p.act);
+            if (p.act == MSC_ACT_GELU_DSAVE) {
+              float d;
+              gelu_both(x, x, d);
+              if (C2) msc_traits<T>::st(C2 + o + e, d);
+            } else {
+              if (C2) msc_traits<T>::st(C2 + o + e, x);
+              x = act_apply(x, p.act);
+            }
             if (Rs) x += msc_traits<T>::ld(Rs + o + e);
             if constexpr (EPX) {
               if (p.dref) x *= act_grad(msc_traits<T>::ld(reinterpret_cast<const T*>(p.dref) + o + e), p.dact);
@@ -1358,7 +1370,7 @@ extern "C" int msc_linear_fwd(const void* x, const void* w, const float* bias, c
                               int M, int N, int K, int act, int dtype, void* stream) {
   MSC_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
-  MSC_CHECK_ARG(K % vec_of(dtype) == 0);
+  MSC_CHECK_ARG(K % vec_of(dtype) == 0 && act >= MSC_ACT_NONE && act <= MSC_ACT_GELU_DSAVE);
   if (!fits32((long)M * K, dtype) || !fits32((long)N * K, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = x; p.B = w; p.C = y; p.C2 = pre; p.res = res; p.bias = bias; p.act = act;
@@ -1375,7 +1387,7 @@ extern "C" int msc_linear_dgrad(const void* dy, const void* wt, const void* res,
                                 int N, int K, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && wt && dx && M > 0 && N > 0 && K > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
-  MSC_CHECK_ARG(N % vec_of(dtype) == 0);
+  MSC_CHECK_ARG(N % vec_of(dtype) == 0 && dact != MSC_ACT_GELU_DSAVE);
   if (!fits32((long)M * N, dtype) || !fits32((long)N * K, dtype)) return MSC_ERR_UNSUPPORTED;
   GemmParams p = base_params();
   p.A = dy; p.B = wt; p.C = dx; p.res = res; p.dref = dact_ref; p.dact = dact; p.colsum = colsum_partial;

@@ -117,6 +117,20 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(y, x);
 }
 
+// gelu(x) and gelu'(x) = Phi(x) + x phi(x) from ONE erf evaluation: A&S 7.1.26 at x / sqrt(2) already holds exp(-x^2 / 2)
+__device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float erfv = copysignf(1.f - q * t * e, x);
+  y = 0.5f * x * (1.f + erfv);                       // the same operations in the same order as act_apply(x, MSC_ACT_GELU)
+  dy = fmaf(x * 0.3989422804014327f, e, 0.5f * (1.f + erfv));
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
     case MSC_ACT_RELU: return x > 0.f ? x : 0.f;
@@ -134,6 +148,7 @@ __device__ __forceinline__ float act_grad(float r, int act) {
     case MSC_ACT_TANH: return 1.f - r * r;
     case MSC_ACT_SIGMOID: return r * (1.f - r);
     case MSC_ACT_GELU: return 0.5f * (1.f + fast_erf(r * 0.70710678118654752f)) + r * 0.3989422804014327f * __expf(-0.5f * r * r);
+    case MSC_ACT_MUL_REF: return r;
     default: return 1.f;
   }
 }

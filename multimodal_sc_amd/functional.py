@@ -51,6 +51,10 @@ _MASK_FROM_X = os.environ.get("MSC_BN_MASK_FROM_X", "1") != "0"   # A/B knob: 0 
 _FUSED_STEM = os.environ.get("MSC_FUSED_STEM", "1") != "0"    # A/B knob: 0 = separate bn_apply / max-pool kernels in the stem
 _STEM_S2D = os.environ.get("MSC_STEM_S2D", "1") != "0"       # A/B knob: 0 = the stem convolution over NHWC with RGB padded to 8 channels
 _FUSED_BIAS = os.environ.get("MSC_FUSED_BIAS", "1") != "0"    # A/B knob: 0 = bias gradients by separate column-sum launches
+# fusion-layer GELU: fc1's forward epilogue stores gelu'(u) (it shares the erf evaluation's exponential) where it used to store u, and
+# fc2's dgrad epilogue multiplies by it instead of evaluating erf + exp per element (A/B knob: 0 = store u, evaluate in the backward)
+_GELU_DSAVE = os.environ.get("MSC_GELU_DSAVE", "1") != "0"
+_GELU_FWD, _GELU_BWD = (L.ACT_GELU_DSAVE, L.ACT_MUL_REF) if _GELU_DSAVE else (L.ACT_GELU, L.ACT_GELU)
 
 
 def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad,
@@ -572,7 +576,7 @@ def _fusion_fwd_two_chains(ctx, x, rt, p, h):
     for c, r0, n, _, _ in chains:
         call("msc_layernorm_fwd", a_x1 + r0 * rD, ln2g, ln2b, a_h2 + r0 * rD, a_st + (2 * M + r0) * 4, a_st + (3 * M + r0) * 4, n, D, LN_EPS, dt, c)
     for c, r0, n, _, _ in chains:
-        call("msc_linear_fwd", a_h2 + r0 * rD, w1, b1, None, a_u + r0 * rF, a_upre + r0 * rF, n, Fh, D, L.ACT_GELU, dt, c)
+        call("msc_linear_fwd", a_h2 + r0 * rD, w1, b1, None, a_u + r0 * rF, a_upre + r0 * rF, n, Fh, D, _GELU_FWD, dt, c)
     for c, r0, n, _, _ in chains:
         call("msc_linear_fwd", a_u + r0 * rF, w2, b2, a_x1 + r0 * rD, a_x2 + r0 * rD, None, n, D, Fh, L.ACT_NONE, dt, c)
     if p.get("last", True):                                       # the final LayerNorm reads the whole batch on the main stream
@@ -635,9 +639,9 @@ def _fusion_bwd_two_chains(ctx, dy):
     rt.side_also_waits = (s2, ev_bs)
     try:
         wgrad(u, dx2, p["fc2w"], p["fc2b"])
-        # fc2's dgrad epilogue applies GELU' (from the saved pre-activation)
+        # fc2's dgrad epilogue applies GELU' (the derivative fc1's forward epilogue stored; MSC_GELU_DSAVE=0: from the pre-activation)
         for c, r0, n, _, _, _ in chains:
-            call("msc_linear_dgrad", a_dx2 + r0 * rD, t2, None, a_upre + r0 * rF, L.ACT_GELU, None, a_dpre + r0 * rF, n, D, Fh, dt, c)
+            call("msc_linear_dgrad", a_dx2 + r0 * rD, t2, None, a_upre + r0 * rF, _GELU_BWD, None, a_dpre + r0 * rF, n, D, Fh, dt, c)
         wgrad(h2, dpre, p["fc1w"], p["fc1b"])
         for c, r0, n, _, _, _ in chains:
             call("msc_linear_dgrad", a_dpre + r0 * rF, t1, None, None, L.ACT_NONE, None, a_dh2 + r0 * rD, n, Fh, D, dt, c)
@@ -684,7 +688,7 @@ class FusionLayerFn(torch.autograd.Function):
         o, P = attention_fwd(rt, qkv, B, T, h, hd)
         x1, _ = linear_fwd(rt, o, p["projw"], p["projb"], L.ACT_NONE, res=x2d)
         h2, mu2, rs2 = layernorm_fwd(rt, x1, p["ln2g"], p["ln2b"])
-        u, upre = linear_fwd(rt, h2, p["fc1w"], p["fc1b"], L.ACT_GELU, want_pre=True)
+        u, upre = linear_fwd(rt, h2, p["fc1w"], p["fc1b"], _GELU_FWD, want_pre=True)
         x2, _ = linear_fwd(rt, u, p["fc2w"], p["fc2b"], L.ACT_NONE, res=x1)
         ctx.save_for_backward(x2d, mu1, rs1, h1, qkv, P, o, x1, mu2, rs2, h2, upre, u)
         ctx.cfg = (rt, p, h, (B, T, D))
@@ -700,7 +704,7 @@ class FusionLayerFn(torch.autograd.Function):
         dx2 = dy.reshape(B * T, D).contiguous()
         # fc2's dgrad epilogue applies GELU' (from the saved pre-activation); fc1's bias gradient = row sums of dpre, which
         # fc1's weight-gradient GEMM produces on the side (no column-sum epilogue + finalize launch on the main chain)
-        dpre = linear_bwd(rt, dx2, u, None, p["fc2w"], p["fc2b"], L.ACT_NONE, prev_act=L.ACT_GELU, prev_ref=upre)
+        dpre = linear_bwd(rt, dx2, u, None, p["fc2w"], p["fc2b"], L.ACT_NONE, prev_act=_GELU_BWD, prev_ref=upre)
         dh2 = linear_bwd(rt, dpre, h2, None, p["fc1w"], p["fc1b"], L.ACT_NONE)
         dx1 = layernorm_bwd(rt, dh2, x1, mu2, rs2, p["ln2g"], p["ln2b"], dadd=dx2)       # + residual branch
         do = linear_bwd(rt, dx1, o, None, p["projw"], p["projb"], L.ACT_NONE)

@@ -14,7 +14,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "msc.h")
 LIB_PATH = os.environ.get("MSC_LIB_PATH") or os.path.join(_HERE, "csrc", "libmsc_hip.so")
 
 MSC_F32, MSC_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID, ACT_GELU_DSAVE, ACT_MUL_REF = 0, 1, 2, 3, 4, 5, 6
 CH_AWGN, CH_RAYLEIGH = 0, 1
 
 _CTYPES = {

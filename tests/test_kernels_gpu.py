@@ -144,6 +144,39 @@ def test_linear_dgrad_fused_act_and_bias(rts, dtype, M, N, K, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 2048, 512), (37, 72, 64)])
+def test_linear_gelu_derivative_save(rts, dtype, M, N, K):
+    """MSC_ACT_GELU_DSAVE: y is bit-identical to MSC_ACT_GELU's y, the side output is gelu'(pre-activation); MSC_ACT_MUL_REF in the
+    dgrad epilogue multiplies by it: same gradient as the evaluate-in-the-backward path within one rounding of the stored derivative"""
+    from multimodal_sc_amd import functional as F, lib as L
+    rt = rts[dtype]
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
+    W, Bp = FakeParam(rt, w, "linear"), FakeParam(rt, b, "vec")
+    y0, pre = F.linear_fwd(rt, dev(x, rt), W, Bp, L.ACT_GELU, want_pre=True)
+    y1, dsv = F.linear_fwd(rt, dev(x, rt), W, Bp, L.ACT_GELU_DSAVE, want_pre=True)
+    assert torch.equal(y0, y1)
+    u = (q(x, dtype) @ q(w, dtype).t() + b).requires_grad_()
+    TF.gelu(u).sum().backward()
+    check("gelu'", dsv, u.grad, tol(dtype))
+    # backward through a following layer [N -> K2]: dx = (dy W2) * gelu'
+    K2 = 64
+    dy, w2 = rnd(M, K2, seed=4), rnd(K2, N, seed=5, scale=1 / math.sqrt(N))
+    W2 = FakeParam(rt, w2, "linear")
+    dx0, dx1 = rt.empty(M, N), rt.empty(M, N)
+    rt.call("msc_linear_dgrad", dev(dy, rt), W2.t, None, pre, L.ACT_GELU, None, dx0, M, K2, N, rt.dt)
+    rt.call("msc_linear_dgrad", dev(dy, rt), W2.t, None, dsv, L.ACT_MUL_REF, None, dx1, M, K2, N, rt.dt)
+    ref = (q(dy, dtype) @ q(w2, dtype)) * u.grad
+    check("dx (derivative evaluated in the backward)", dx0, ref, tol(dtype) * 2)
+    check("dx (stored derivative)", dx1, ref, tol(dtype) * 2)
+    if dtype == "f32":
+        check("two paths, fp32", dx1, dx0.float().cpu(), 1e-6)
+    # the element-wise activation backward accepts the stored derivative too
+    d = rt.empty(M, N)
+    rt.call("msc_act_bwd", dev(dy @ w2, rt), dsv, d, M * N, L.ACT_MUL_REF, rt.dt)
+    check("act_bwd", d, q(dy @ w2, dtype) * q(dsv.float().cpu(), dtype), tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_residual(rts, dtype):
     from multimodal_sc_amd import functional as F
     rt = rts[dtype]
