@@ -185,12 +185,17 @@ def host_inputs_leg(args, cfg, model, trainer, dev_batch, ms_device_resident):
     ppo = {k: v.cpu().numpy() for k, v in dev_batch["ppo"].items()}
     st = FrameStager(model.rt, src, B, extra_fn=lambda k: ppo)
 
+    own = [None]
+
     def step():
-        b = st.next()
+        b = st.next(image_out=own[0]["image"] if own[0] is not None else None)      # camera bytes decoded straight into the step's input
         st.prefetch()
         feed = {k: b[k] for k in ("image", "points", "state") if k in b}        # same keys as the device-resident batch
         feed.update(snr_db=dev_batch["snr_db"], noise=None, fading=None, ppo=dict(b["extra"]))
-        return trainer.step(feed)
+        terms = trainer.step(feed)
+        if own[0] is None:
+            own[0] = trainer.input_buffers(feed)
+        return terms
 
     for _ in range(max(args.warmup, 4)):
         step()
@@ -276,6 +281,16 @@ def allreduce_probe(model, trainer, dist, torch, reps=5):
         ms = float(t.item()) * 1e3
         out[name] = {"mbytes": (hi - lo) * 4 / 1e6, "ms": ms, "GB_per_s": (hi - lo) * 4 / 1e9 / (ms * 1e-3)}
     return out
+
+
+def _flat(batch, prefix=""):
+    """(key, tensor) pairs of a nested batch dict in a fixed order"""
+    for k in sorted(batch):
+        v = batch[k]
+        if isinstance(v, dict):
+            yield from _flat(v, prefix + k + ".")
+        elif hasattr(v, "data_ptr"):
+            yield prefix + k, v
 
 
 def spawn_ranks(args, argv):
@@ -390,6 +405,13 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         trainer.step(batch)
+    # the synthetic batch lives in the trainer's own input buffers from here on (what a frame source writes into: no device-to-device
+    # staging copy inside a step); None while no launch list is recorded (fewer warm-up steps than the recorder needs, MSC_REPLAY=0)
+    own = trainer.input_buffers(batch) if os.environ.get("MSC_BENCH_OWN_INPUTS", "1") != "0" else None     # (0: A/B knob)
+    if own is not None:
+        for (k, d), (_, v) in zip(_flat(own), _flat(batch)):
+            d.copy_(v)
+        batch = own
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -407,6 +429,7 @@ def main(argv=None):
         "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
+        "inputs": "HBM-resident in the trainer's input buffers" if own is not None else "HBM-resident, copied into the trainer's input buffers every step",
         "config": {"workload": f"{args.config}: camera 3x{cfg.img_size}x{cfg.img_size}"
                                + (f" + {cfg.n_points}-pt LiDAR BEV" if cfg.use_lidar else "") + (" + ego-state" if cfg.use_state else "")
                                + f", fusion transformer T={cfg.n_tokens} d={cfg.d_model} L={cfg.n_layers}, {cfg.channel.upper()} 10 dB, PPO head",

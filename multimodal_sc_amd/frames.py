@@ -168,9 +168,10 @@ class FrameStager:
         self._slot_of[k] = slot
         self._issued += 1
 
-    def next(self):
+    def next(self, image_out=None):
         """-> dict(image fp32 [B,3,H,W] in [0,1], frames_u8, points, state, action, extra{...}): device tensors of the next batch,
-        valid until the batch after the next one is taken"""
+        valid until the batch after the next one is taken.  image_out: decode the camera bytes into this tensor instead of the stager's
+        own (e.g. Trainer.input_buffers(...)["image"]: the step then has no staging copy of the largest input)"""
         k = self._taken
         assert k < self._issued, "call prefetch() once per next()"
         rt, st, slot = self.rt, self.stage[k % 2], self._slot_of.pop(k)
@@ -178,6 +179,10 @@ class FrameStager:
         self._free.put(slot)               # (the filler waits for the copy's event before it writes the slot again)
         B, H, W, _ = st["camera"].shape
         img = self.image[k % 2]
+        if image_out is not None:
+            if tuple(image_out.shape) != tuple(img.shape) or image_out.dtype != img.dtype or not image_out.is_contiguous():
+                raise ValueError(f"image_out must be a contiguous {tuple(img.shape)} {img.dtype} tensor")
+            img = image_out
         L.call("msc_frames_u8_to_nchw", st["camera"], img, B, H, W, rt.stream)
         self._taken += 1
         out = {"image": img, "frames_u8": st["camera"]}

@@ -35,6 +35,8 @@ def test_staged_batches_equal_the_source_bytes_and_feed_the_step(cuda, tmp_path)
     ppo_host = [{"actions": rng.integers(0, cfg.n_actions, B).astype(np.int64), "old_logp": (-np.log(cfg.n_actions) + 0.1 * rng.standard_normal(B)).astype(np.float32),
                  "adv": rng.standard_normal(B).astype(np.float32), "ret": rng.standard_normal(B).astype(np.float32)} for _ in range(nb)]
 
+    direct = [0]
+
     def run(staged):
         torch.manual_seed(0)
         m = MultimodalSC(cfg, dtype="bf16", device="cuda:0", seed=3)
@@ -42,10 +44,15 @@ def test_staged_batches_equal_the_source_bytes_and_feed_the_step(cuda, tmp_path)
         snr = torch.full((B,), 10.0, device="cuda:0")
         st = FrameStager(m.rt, log, B, extra_fn=lambda k: ppo_host[k % len(ppo_host)]) if staged else None
         seen = []
+        batch = None
         for k in range(nb):
             idx = (np.arange(B) + k * B) % log.n
             if staged:
-                b = st.next()
+                # once the trainer has recorded its launch list, the camera bytes are decoded straight into the step's own image input
+                own = tr.input_buffers(batch) if batch is not None else None
+                b = st.next(image_out=own["image"] if own is not None else None)
+                assert own is None or b["image"].data_ptr() == own["image"].data_ptr()
+                direct[0] += own is not None
                 st.prefetch()
                 seen.append({kk: b[kk].clone() for kk in ("frames_u8", "image", "points", "state", "action")})
                 batch = {"image": b["image"], "points": b["points"], "state": b["state"], "snr_db": snr, "noise": None, "fading": None,
@@ -64,6 +71,7 @@ def test_staged_batches_equal_the_source_bytes_and_feed_the_step(cuda, tmp_path)
         return m.params.P.clone(), seen
 
     P_staged, seen = run(True)
+    assert direct[0] >= 2, "the decode-into-the-input-buffer path was not exercised"
     for k, b in enumerate(seen):
         idx = (np.arange(B) + k * B) % log.n
         cam = np.asarray(log.arrays["camera"][idx])

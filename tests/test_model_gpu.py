@@ -446,8 +446,8 @@ def test_launch_replay_matches_eager(cuda, monkeypatch, name, B, chains):
     """Trainer.step through the C-side launch replay (default: two eager warm-up steps, one recorded step, then replays of the
     recorded launch list from csrc/replay.hip) must leave parameters, Adam moments and loss terms BIT-identical to the eager
     Python loop (MSC_REPLAY=0): same kernels, same streams, same order; step and noise-draw numbers come from device counters.
-    Also: a second batch of the same shape goes through the static input buffers, and a batch of another shape records its own
-    program without disturbing the first."""
+    Also: a second batch of the same shape goes through the static input buffers (copied by step(), or written there by the caller:
+    Trainer.input_buffers), and a batch of another shape records its own program without disturbing the first."""
     from multimodal_sc_amd import functional as F
     from multimodal_sc_amd.model import MultimodalSC, named_config
     from multimodal_sc_amd.trainer import Trainer
@@ -467,7 +467,18 @@ def test_launch_replay_matches_eager(cuda, monkeypatch, name, B, chains):
         assert tr.use_replay == (mode == "1")
         sse = []
         for i in range(7):
-            terms = tr.step(batches[i % 2] if i != 4 else other)
+            feed = batches[i % 2] if i != 4 else other
+            if mode == "1" and i >= 5:
+                # a frame source that writes into the trainer's own input buffers: no staging copy, same result
+                own = tr.input_buffers(feed)
+                assert own is not None and own["image"].data_ptr() != feed["image"].data_ptr()
+                for k in ("image", "points", "state", "snr_db"):
+                    if torch.is_tensor(feed.get(k)):
+                        own[k].copy_(feed[k])
+                for k, v in feed["ppo"].items():
+                    own["ppo"][k].copy_(v)
+                feed = own
+            terms = tr.step(feed)
             sse.append(terms["sse"].clone())
         torch.cuda.synchronize()
         if mode == "1":
