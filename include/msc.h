@@ -95,6 +95,15 @@ int msc_stem_s2d_conv_wgrad(const void* xs, const void* dy, float* dw_s2d, float
  * re-reads its activation for the mask nor writes a separate masked copy for its identity branch. */
 int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, const void* relu_ref, void* dx, int B, int H, int W,
                      int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream);
+/* msc_conv2d_dgrad whose output dx is the gradient w.r.t. the output of a BatchNorm + ReLU (no residual): the epilogue also does the
+ * STATISTICS PASS of that BatchNorm's backward.  bn_x: that BatchNorm's input (the previous convolution's output, [B,H,W,Cin]);
+ * bn_stats: fp32 [4][Cin] mean, rstd, scale, shift (msc_bn_finalize); bn_partial: fp32 [msc_conv2d_dgrad_stat_rows(B*H*W, Cin, dtype)][2][Cin]
+ * per-row-block sums of dz and dz*xhat, dz = dx * [bn_x*scale+shift > 0] (dx as stored, i.e. rounded to T).  dx itself is stored unmasked;
+ * msc_bn_bwd_from_partials finishes the job.  Stride-1 (row-major tiled) launches only: MSC_ERR_UNSUPPORTED otherwise. */
+int64_t msc_conv2d_dgrad_stat_rows(int64_t rows, int cin, int dtype);
+int msc_conv2d_dgrad_bnstat(const void* dy, const void* wt, const void* res, void* dx, const void* bn_x, const float* bn_stats,
+                            float* bn_partial, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                            float* ws, int64_t ws_bytes, int dtype, void* stream);
 /* dw (fp32, OHWI) = sum over pixels dy^T x.  accumulate!=0 adds to dw.  ws: see msc_wgrad_workspace_bytes. */
 int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,
                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
@@ -164,6 +173,11 @@ int64_t msc_bn_bwd_workspace_bytes(int C);
 int msc_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                const float* gamma, const float* scale, const float* shift, void* dx, void* dres, float* dgamma,
                float* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate, int dtype, void* stream);
+/* msc_bn_bwd (relu = 1, mask from x*scale+shift, no dres) with the statistics pass already done by msc_conv2d_dgrad_bnstat:
+ * partial = its bn_partial, nblk = its row count.  One finalize + one apply launch. */
+int msc_bn_bwd_from_partials(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* scale,
+                             const float* shift, const float* partial, int nblk, void* dx, float* dgamma, float* dbeta, float* ws,
+                             int64_t rows, int C, int accumulate, int dtype, void* stream);
 /* ImageEncoder stem, BN + ReLU + max-pool (KxK / S, pad P) fused: the post-activation map is never materialised.
  * fwd: x = conv output [B,H,W,C], scale/shift from msc_bn_finalize -> pooled y [B,Ho,Wo,C], arg-max tap ids idx (same values
  *      and tie-breaks as msc_bn_apply + msc_maxpool_fwd) and xsel [B,Ho,Wo,C] = the conv output at each window's arg-max.

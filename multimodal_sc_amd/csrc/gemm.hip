@@ -52,6 +52,10 @@ struct GemmParams {
   int xcd_split;                // split-K launches: all tiles of one K slice on one XCD (see the kernel's index mapping)
   const void* dref; int dact;   // epilogue: multiply by act'(dref[m][n]) (fused activation backward)
   float* colsum;                // epilogue: per-row-block column sums of the stored output, [tile_m][N]
+  // epilogue (conv dgrad): the stored output is dy of the BatchNorm + ReLU that produced this layer's input.  bnx = that BatchNorm's
+  // input (the previous conv's output, [M][N]), bnstat = its [4][N] mean, rstd, scale, shift, bnpart = [tile_m][2][N] per-row-block
+  // sums of dz and dz*xhat with dz = dy * [x*scale+shift > 0] — the statistics pass of msc_bn_bwd, done where dy is produced
+  const void* bnx; const float* bnstat; float* bnpart;
   int dephase_first;            // ... and the number of workgroups that make up round 1
   int dephase;                  // GEMM_DEPHASE experiment build: s_sleep units (64 clk) the odd residency slot of each CU waits in round 1
 };
@@ -111,7 +115,18 @@ extern "C" int msc_debug_gemm_stamps(unsigned long long* host_out, int nwg) {
   if (!g_stamp_buf) return MSC_ERR_BAD_ARG;
   return hipMemcpy(host_out, g_stamp_buf, (size_t)nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
 }
+// epilogue detail (second record per workgroup, GEMM_STAMP_EP_OFF records further on): [0] wait at the barrier that ends the K loop,
+// [1] BatchNorm-statistics part, [2] accumulators -> slab incl. its barrier (summed over passes), [3] slab -> registers -> global stores
+// issued (summed), [4] barrier between passes (summed; __syncthreads waits for the pass's stores), [5] column-sum tail
+#define GEMM_STAMP_EP_OFF (1 << 19)
+extern "C" int msc_debug_gemm_stamps_ep(unsigned long long* host_out, int nwg) {
+  if (!g_stamp_buf) return MSC_ERR_BAD_ARG;
+  return hipMemcpy(host_out, g_stamp_buf + (size_t)GEMM_STAMP_EP_OFF * 8, (size_t)nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? MSC_OK : MSC_ERR_LAUNCH;
+}
 #define STAMP_NOW() __builtin_amdgcn_s_memtime()
+#define EP_STAMP(acc) do { const unsigned long long n_ = STAMP_NOW(); acc += n_ - st_e; st_e = n_; } while (0)
+#else
+#define EP_STAMP(acc) ((void)0)
 #endif
 
 template <int MODE> struct mode_is_kmajor { static constexpr bool value = (MODE == OPM_DENSE_K || MODE == OPM_CONV_FWD || MODE == OPM_CONV_DGRAD); };
@@ -373,7 +388,9 @@ struct Sched { KStep ks; int nk, s_kw0, s_step; };
 // NTHR: 512 (8 waves) for the 256-row tiles and for the 128x128 tile of the k-major / dense kernels (wave tile 32x64: four
 // waves per SIMD at two workgroups per CU — measured 3 % faster over the path's shapes, 15-20 % on the weight gradients),
 // 256 (4 waves, 2x2) otherwise.
-template <typename T, int AMODE, int BMODE, int BM, int BN, bool EPX, int KB, int NSTAGE, bool PERSIST, int NTHR>
+// EPX: 0 plain epilogue, 1 + activation backward (dref) / column sums, 2 + BatchNorm-backward statistics (bnpart) — an instantiation of its
+// own: its per-channel constants and second sum set cost ~45 registers the other extended epilogues (128-register budget) do not have
+template <typename T, int AMODE, int BMODE, int BM, int BN, int EPX, int KB, int NSTAGE, bool PERSIST, int NTHR>
 __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 : 2)) void gemm_kernel(const GemmParams p) {
   constexpr int KT = KB / sizeof(T);
   constexpr int NWN = BN == 256 ? 4 : 2;        // waves along N: 256x256 -> 2x4 (wave tile 128x64), 256x128 -> 4x2, else 2x2
@@ -743,6 +760,10 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
     st_k += st_k1 - st_k0;
 #endif
     if constexpr (!PERSIST) __syncthreads();   // the slab aliases the ring
+#ifdef GEMM_STAMP
+    unsigned long long st_e = st_k1, se0 = 0, se1 = 0, se2 = 0, se3 = 0, se4 = 0, se5 = 0;
+#endif
+    EP_STAMP(se0);
 
 #define EP_SYNC()                                                                                   \
   do {                                                                                              \
@@ -799,6 +820,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
     EP_SYNC();
   }
 
+  EP_STAMP(se1);
   // (2) accumulators -> LDS slab (fp32, SLAB_ROWS rows per pass) -> 16-byte coalesced global stores with the fused
   //     bias / pre-activation copy / activation / residual applied on whole vectors
   float* slab = reinterpret_cast<float*>(ep_mem);
@@ -807,8 +829,21 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
                        : reinterpret_cast<char*>(reinterpret_cast<T*>(p.C) + zo * p.sc_o + zi * p.sc_i);
   constexpr int PASSES = BM > SLAB_ROWS ? BM / SLAB_ROWS : 1;   // SLAB_ROWS output rows per pass (BM = 64: the whole tile)
   float csum[16 / sizeof(T)];   // this thread's column chunk is the same in every iteration (NSTORE % (BN/VEC) == 0)
+  float csum2[16 / sizeof(T)];
 #pragma unroll
-  for (int e = 0; e < (int)(16 / sizeof(T)); ++e) csum[e] = 0.f;
+  for (int e = 0; e < (int)(16 / sizeof(T)); ++e) { csum[e] = 0.f; csum2[e] = 0.f; }
+  // EPX 2: the four per-channel constants (mean, rstd, scale, shift) of the tile's BN columns wait in LDS behind the slab (the rest of the
+  // dead operand ring) — as registers they would be 4 x VEC per thread on top of the two sum sets, past the 128-register budget
+  float* const bnc = reinterpret_cast<float*>(ep_mem + EP_BYTES);     // [4][BN]
+  if constexpr (EPX == 2) {
+    static_assert(PERSIST || EP_BYTES + 4 * BN * 4 <= SMEM_BYTES, "no room behind the slab for the BatchNorm constants");
+    if (tid < BN) {
+      const int n = n0 + tid;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bnc[k * BN + tid] = n < p.N ? p.bnstat[(long)k * p.N + n] : 0.f;
+    }
+    // (visible to the storing threads after the barrier that follows the first slab write)
+  }
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
@@ -823,6 +858,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
           slab[(rbase + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WN + j * 32 + lr] = p.alpha * acc[i][j][r];
     }
     EP_SYNC();
+    EP_STAMP(se2);
     if (!is_storer) {
     } else if (f32out) {
       constexpr int CPRW = BN / 4;
@@ -909,6 +945,17 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
 #pragma unroll
               for (int e = 0; e < VEC; ++e) csum[e] += v[e];
             }
+            if constexpr (EPX == 2) {
+              vecf<T> vx;
+              vx.load(reinterpret_cast<const T*>(p.bnx) + o);
+              const float* kc = bnc + cc * VEC;
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                const float dz = fmaf(vx.v[e], kc[2 * BN + e], kc[3 * BN + e]) > 0.f ? msc_traits<T>::rnd(v[e]) : 0.f;    // dy as the consumer reads it back
+                csum[e] += dz;
+                csum2[e] += dz * (vx.v[e] - kc[e]) * kc[BN + e];
+              }
+            }
           }
 #pragma unroll
           for (int e = 0; e < VEC; ++e) vo.v[e] = v[e];
@@ -928,35 +975,57 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
             if constexpr (EPX) {
               if (p.dref) x *= act_grad(msc_traits<T>::ld(reinterpret_cast<const T*>(p.dref) + o + e), p.dact);
               if (p.colsum) csum[e] += x;
+              if constexpr (EPX == 2) {
+                const float xv = msc_traits<T>::ld(reinterpret_cast<const T*>(p.bnx) + o + e);
+                const float* kc = bnc + cc * VEC + e;
+                const float dz = fmaf(xv, kc[2 * BN], kc[3 * BN]) > 0.f ? msc_traits<T>::rnd(x) : 0.f;
+                csum[e] += dz;
+                csum2[e] += dz * (xv - kc[0]) * kc[BN];
+              }
             }
             msc_traits<T>::st(dst + e, x);
           }
         }
       }
     }
+    EP_STAMP(se3);
     if (ps + 1 < PASSES) EP_SYNC();
+    EP_STAMP(se4);
   }
-  if (EPX && p.colsum && !f32out) {
+  if (EPX && (p.colsum || (EPX == 2 && p.bnpart)) && !f32out) {
     // fixed-order reduction of the per-thread column sums over the NTHR/(BN/VEC) threads that share a column chunk
     constexpr int VEC = 16 / sizeof(T);
     constexpr int CPRW = BN / VEC, NR = NSTORE / CPRW;
     static_assert(NR <= SLAB_ROWS, "column-sum scratch must fit the slab");
-    EP_SYNC();
     const int cc = stid % CPRW, rr = stid / CPRW;
-    if (is_storer) {
+    auto reduce_cols = [&](const float (&cs)[VEC], float* dst_row) {
+      EP_SYNC();
+      if (is_storer) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) slab[rr * BN + cc * VEC + e] = csum[e];
-    }
-    EP_SYNC();
-    if (is_storer && stid < BN && n0 + stid < p.N) {
-      float a = 0.f;
-      for (int r = 0; r < NR; ++r) a += slab[r * BN + stid];
-      p.colsum[(long)tile_m * p.N + n0 + stid] = a;
+        for (int e = 0; e < VEC; ++e) slab[rr * BN + cc * VEC + e] = cs[e];
+      }
+      EP_SYNC();
+      if (is_storer && stid < BN && n0 + stid < p.N) {
+        float a = 0.f;
+        for (int r = 0; r < NR; ++r) a += slab[r * BN + stid];
+        dst_row[n0 + stid] = a;
+      }
+    };
+    if (EPX == 2 && p.bnpart) {
+      reduce_cols(csum, p.bnpart + (long)tile_m * 2 * p.N);
+      reduce_cols(csum2, p.bnpart + (long)tile_m * 2 * p.N + p.N);
+    } else {
+      reduce_cols(csum, p.colsum + (long)tile_m * p.N);
     }
   }
     if constexpr (PERSIST) EP_SYNC();   // the slab is free again before the next tile's epilogue touches it
 #ifdef GEMM_STAMP
+    EP_STAMP(se5);
     st_ep += STAMP_NOW() - st_k1;
+    if (p.stamps && tid == 0) {
+      unsigned long long* o = p.stamps + ((size_t)GEMM_STAMP_EP_OFF + (size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+      o[0] = se0; o[1] = se1; o[2] = se2; o[3] = se3; o[4] = se4; o[5] = se5;
+    }
 #endif
   }   // tile loop
 #ifdef GEMM_STAMP
@@ -1017,7 +1086,8 @@ __global__ __launch_bounds__(64 * RY) void splitk_reduce_kernel(const float* __r
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int ns, long M, int N, T* __restrict__ y,
                                                             const T* __restrict__ res, float* __restrict__ stats, int RB,
-                                                            const T* __restrict__ relu_ref) {
+                                                            const T* __restrict__ relu_ref, const T* __restrict__ bnx = nullptr,
+                                                            const float* __restrict__ bnstat = nullptr) {
   __shared__ float red[2][16][64];
   const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + c4 * 4;
@@ -1034,8 +1104,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
       }
       float v[4] = {a.x, a.y, a.z, a.w};
-      s1[0] += v[0]; s1[1] += v[1]; s1[2] += v[2]; s1[3] += v[3];
-      s2[0] += v[0] * v[0]; s2[1] += v[1] * v[1]; s2[2] += v[2] * v[2]; s2[3] += v[3] * v[3];
+      if (!bnx) {
+        s1[0] += v[0]; s1[1] += v[1]; s1[2] += v[2]; s1[3] += v[3];
+        s2[0] += v[0] * v[0]; s2[1] += v[1] * v[1]; s2[2] += v[2] * v[2]; s2[3] += v[3] * v[3];
+      }
       if (res) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += msc_traits<T>::ld(res + e + j);
@@ -1043,6 +1115,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
       if (relu_ref) {     // dgrad: ReLU backward of the activation that produced this layer's input (relu_ref = that activation)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = msc_traits<T>::ld(relu_ref + e + j) > 0.f ? v[j] : 0.f;
+      }
+      if (bnx) {          // dgrad: BatchNorm-backward sums of the producer of this layer's input (see GemmParams::bnpart)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xv = msc_traits<T>::ld(bnx + e + j);
+          const float dz = fmaf(xv, bnstat[2 * N + n + j], bnstat[3 * N + n + j]) > 0.f ? msc_traits<T>::rnd(v[j]) : 0.f;
+          s1[j] += dz;
+          s2[j] += dz * (xv - bnstat[n + j]) * bnstat[N + n + j];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) msc_traits<T>::st(y + e + j, v[j]);
@@ -1090,7 +1171,7 @@ extern "C" int64_t msc_conv2d_fwd_stat_rows(int64_t rows, int cout, int dtype) {
   return cdiv(rows, tile_for(rows, cout, 1, OPM_CONV_FWD, OPM_DENSE_K, dtype).bm);
 }
 
-template <typename T, int AMODE, int BMODE, bool EPX = false>
+template <typename T, int AMODE, int BMODE, int EPX = 0>
 static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   constexpr int DT = std::is_same<T, float>::value ? MSC_F32 : MSC_BF16;
   const long zs = (long)batch * p.nsplit;
@@ -1098,7 +1179,7 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   if (!g_stamp_buf) (void)hipMalloc(&g_stamp_buf, (size_t)(1 << 20) * 8 * sizeof(unsigned long long));
   const_cast<GemmParams&>(p).stamps = g_stamp_buf;
 #endif
-  const bool big = p.nsplit == 1 && !p.xcd_split && !p.stats && !p.colsum;
+  const bool big = p.nsplit == 1 && !p.xcd_split && !p.stats && !p.colsum && !p.bnpart;
   const mscplan::Tile t = tile_for(p.M, p.N, zs, AMODE, BMODE, DT, p.K, big, p.bm_cap ? p.bm_cap : 256);
   const int bm = t.bm, bn = t.bn;
   GemmParams q = p;
@@ -1124,7 +1205,7 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
     }
   }
 #endif
-  if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
+  if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value && EPX != 2) {     // (EPX 2: never `big`)
     if (bm == 256) {     // persistent: one workgroup per CU walks the tiles
       const int ntiles = cdiv(p.M, 256) * cdiv(p.N, bn);
       const int ncu = num_cus();
@@ -1164,7 +1245,7 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   return msc_launch_status();
 }
 
-template <int AMODE, int BMODE, bool EPX = false>
+template <int AMODE, int BMODE, int EPX = 0>
 static int launch_gemm_dt(const GemmParams& p, int batch, int dtype, hipStream_t st) {
   if (dtype == MSC_F32) return launch_gemm<float, AMODE, BMODE, EPX>(p, batch, st);
   if (dtype == MSC_BF16) return launch_gemm<bf16_t, AMODE, BMODE, EPX>(p, batch, st);
@@ -1239,15 +1320,21 @@ static int set_conv_geom(GemmParams& p, int B, int H, int W, int C, int Ho, int 
 // shared tail of msc_conv2d_fwd / msc_conv2d_dgrad: split-K launch + finish when it pays and the workspace allows
 template <int AMODE>
 static int launch_conv_maybe_split(GemmParams& p, void* out, const void* res, float* stats, float* ws, int64_t ws_bytes, int dtype,
-                                   hipStream_t st, const void* relu_ref = nullptr) {
+                                   hipStream_t st, const void* relu_ref = nullptr, const void* bnx = nullptr, const float* bnstat = nullptr) {
   mscplan::ConvSplit cs = mscplan::conv_split(p.M, p.N, p.K, dtype == MSC_F32);
   if (AMODE == OPM_CONV_DGRAD && p.cls) cs.ns = 1;
   if (cs.ns <= 1 || !ws || ws_bytes < (int64_t)cs.ns * p.M * p.N * 4) {
     if constexpr (AMODE == OPM_CONV_DGRAD) {
+      if (bnx) {           // un-split: the extended epilogue also sums dz, dz*xhat for the BatchNorm behind this layer's input
+        p.dref = relu_ref;
+        p.dact = MSC_ACT_RELU;
+        p.bnx = bnx; p.bnstat = bnstat; p.bnpart = stats;
+        return launch_gemm_dt<AMODE, OPM_DENSE_K, 2>(p, 1, dtype, st);
+      }
       if (relu_ref) {      // un-split: the extended epilogue multiplies by relu'(relu_ref) after the residual add
         p.dref = relu_ref;
         p.dact = MSC_ACT_RELU;
-        return launch_gemm_dt<AMODE, OPM_DENSE_K, true>(p, 1, dtype, st);
+        return launch_gemm_dt<AMODE, OPM_DENSE_K, 1>(p, 1, dtype, st);
       }
     }
     return launch_gemm_dt<AMODE, OPM_DENSE_K>(p, 1, dtype, st);
@@ -1263,10 +1350,10 @@ static int launch_conv_maybe_split(GemmParams& p, void* out, const void* res, fl
   const dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, bm0));
   if (dtype == MSC_F32)
     hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (float*)out, (const float*)res, stats, bm0,
-                       (const float*)relu_ref);
+                       (const float*)relu_ref, (const float*)bnx, bnstat);
   else
     hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, grid, dim3(256), 0, st, ws, ns, (long)p.M, p.N, (bf16_t*)out, (const bf16_t*)res, stats, bm0,
-                       (const bf16_t*)relu_ref);
+                       (const bf16_t*)relu_ref, (const bf16_t*)bnx, bnstat);
   return msc_launch_status();
 }
 
@@ -1321,8 +1408,9 @@ extern "C" int msc_stem_s2d_conv_wgrad(const void* xs, const void* dy, float* dw
                       launch_gemm_dt<OPM_DENSE_MN, OPM_CONV_WGRAD>, 64);
 }
 
-extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, const void* relu_ref, void* dx, int B, int H, int W,
-                                int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream) {
+static int conv2d_dgrad_impl(const void* dy, const void* wt, const void* res, const void* relu_ref, void* dx, const void* bn_x, const float* bn_stats,
+                            float* bn_partial, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                            int64_t ws_bytes, int dtype, void* stream) {
   MSC_CHECK_ARG(dy && wt && dx && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   MSC_CHECK_ARG(Cout >= vec_of(dtype) && ilog2_exact(Cout) >= 0 && Cin > 0 && ilog2_exact(stride) >= 0);
@@ -1345,7 +1433,25 @@ extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res,
     // class — measured 67 -> 32 us)
     if (p.cMc % 128 != 0 && p.cMc % 64 == 0) p.bm_cap = 64;
   }
-  return launch_conv_maybe_split<OPM_CONV_DGRAD>(p, dx, res, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream, relu_ref);
+  if (bn_x && p.cls) return MSC_ERR_UNSUPPORTED;      // the statistics rows follow the NHWC row tiles: stride-1 (and odd-size strided) launches
+  return launch_conv_maybe_split<OPM_CONV_DGRAD>(p, dx, res, bn_partial, ws, ws_bytes, dtype, (hipStream_t)stream, relu_ref, bn_x, bn_stats);
+}
+
+extern "C" int msc_conv2d_dgrad(const void* dy, const void* wt, const void* res, const void* relu_ref, void* dx, int B, int H, int W,
+                                int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, int64_t ws_bytes, int dtype, void* stream) {
+  return conv2d_dgrad_impl(dy, wt, res, relu_ref, dx, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, dtype, stream);
+}
+
+// rows of the BatchNorm-backward partial buffer msc_conv2d_dgrad_bnstat writes for a gradient of `rows` pixels x `cin`
+extern "C" int64_t msc_conv2d_dgrad_stat_rows(int64_t rows, int cin, int dtype) {
+  return cdiv(rows, tile_for(rows, cin, 1, OPM_CONV_DGRAD, OPM_DENSE_K, dtype).bm);
+}
+
+extern "C" int msc_conv2d_dgrad_bnstat(const void* dy, const void* wt, const void* res, void* dx, const void* bn_x, const float* bn_stats,
+                                       float* bn_partial, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                       float* ws, int64_t ws_bytes, int dtype, void* stream) {
+  MSC_CHECK_ARG(bn_x && bn_stats && bn_partial && Cin % 4 == 0);
+  return conv2d_dgrad_impl(dy, wt, res, nullptr, dx, bn_x, bn_stats, bn_partial, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, dtype, stream);
 }
 
 extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, int64_t ws_bytes, int B, int H,
@@ -1392,7 +1498,7 @@ extern "C" int msc_linear_dgrad(const void* dy, const void* wt, const void* res,
   GemmParams p = base_params();
   p.A = dy; p.B = wt; p.C = dx; p.res = res; p.dref = dact_ref; p.dact = dact; p.colsum = colsum_partial;
   p.M = M; p.N = K; p.K = N; p.lda = N; p.ldb = N; p.ldc = K;
-  if (dact_ref || colsum_partial) return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K, true>(p, 1, dtype, (hipStream_t)stream);
+  if (dact_ref || colsum_partial) return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K, 1>(p, 1, dtype, (hipStream_t)stream);
   return launch_gemm_dt<OPM_DENSE_K, OPM_DENSE_K>(p, 1, dtype, (hipStream_t)stream);
 }
 

@@ -28,11 +28,13 @@ template <> struct msc_traits<float> {
   static constexpr int VEC = 4;  // elements per 16-byte chunk
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }     // the value a store of v reads back as
 };
 template <> struct msc_traits<bf16_t> {
   static constexpr int VEC = 8;
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  static __device__ __forceinline__ float rnd(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 };
 
 // 16-byte vector of T unpacked to floats

@@ -635,23 +635,28 @@ extern "C" int msc_bn_apply(const void* x, const float* scale, const float* shif
 
 extern "C" int64_t msc_bn_bwd_workspace_bytes(int C) { return (int64_t)(BN_MAX_BLOCKS + 1) * 2 * C * 4; }
 
+// partial_in / nblk_in: the statistics pass was done by the kernel that produced dy (msc_conv2d_dgrad_bnstat): [nblk_in][2][C] row-block sums
 template <typename T>
 static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                     const float* gamma, const float* scale, const float* shift, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, int64_t rows,
-                    int C, int relu, int accumulate, hipStream_t st) {
+                    int C, int relu, int accumulate, hipStream_t st, const float* partial_in = nullptr, int nblk_in = 0) {
   constexpr int VEC = msc_traits<T>::VEC;
   if (C % VEC || C / VEC > 256) return MSC_ERR_BAD_ARG;
   const int ncx = C / VEC, nty = 256 / ncx;
   if (nty < 1 || (long)nty * C > 2048) return MSC_ERR_BAD_ARG;
-  int nblk = cdiv(rows, 128);
-  if (nblk > BN_MAX_BLOCKS) nblk = BN_MAX_BLOCKS;
-  const int rpb = cdiv(rows, nblk);
-  nblk = cdiv(rows, rpb);
-  float* partial = ws;
   float* sums = ws + (long)BN_MAX_BLOCKS * 2 * C;  // [2][C]
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y,
-                     mean, rstd, scale, shift, partial, (long)rows, C, relu, rpb);
-  launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
+  if (partial_in) {
+    launch_fin_sums(partial_in, nblk_in, C, sums, sums + C, dbeta, dgamma, accumulate, st);
+  } else {
+    int nblk = cdiv(rows, 128);
+    if (nblk > BN_MAX_BLOCKS) nblk = BN_MAX_BLOCKS;
+    const int rpb = cdiv(rows, nblk);
+    nblk = cdiv(rows, rpb);
+    float* partial = ws;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y,
+                       mean, rstd, scale, shift, partial, (long)rows, C, relu, rpb);
+    launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
+  }
   const long nvec = rows * C / VEC;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dy, (const T*)x,
                      (const T*)y, mean, rstd, gamma, scale, shift, sums, sums + C, (T*)dx, (T*)dres, nvec, C, relu,
@@ -670,6 +675,18 @@ extern "C" int msc_bn_bwd(const void* dy, const void* x, const void* y, const fl
     return bn_bwd_t<float>(dy, x, y, mean, rstd, gamma, scale, shift, dx, dres, dgamma, dbeta, ws, rows, C, relu, accumulate, st);
   if (dtype == MSC_BF16)
     return bn_bwd_t<bf16_t>(dy, x, y, mean, rstd, gamma, scale, shift, dx, dres, dgamma, dbeta, ws, rows, C, relu, accumulate, st);
+  return MSC_ERR_BAD_ARG;
+}
+
+extern "C" int msc_bn_bwd_from_partials(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* scale,
+                                        const float* shift, const float* partial, int nblk, void* dx, float* dgamma, float* dbeta, float* ws,
+                                        int64_t rows, int C, int accumulate, int dtype, void* stream) {
+  MSC_CHECK_ARG(dy && x && mean && rstd && gamma && scale && shift && partial && nblk > 0 && dx && dgamma && dbeta && ws && rows > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSC_F32)
+    return bn_bwd_t<float>(dy, x, nullptr, mean, rstd, gamma, scale, shift, dx, nullptr, dgamma, dbeta, ws, rows, C, 1, accumulate, st, partial, nblk);
+  if (dtype == MSC_BF16)
+    return bn_bwd_t<bf16_t>(dy, x, nullptr, mean, rstd, gamma, scale, shift, dx, nullptr, dgamma, dbeta, ws, rows, C, 1, accumulate, st, partial, nblk);
   return MSC_ERR_BAD_ARG;
 }
 

@@ -53,16 +53,23 @@ _STEM_S2D = os.environ.get("MSC_STEM_S2D", "1") != "0"       # A/B knob: 0 = the
 _FUSED_BIAS = os.environ.get("MSC_FUSED_BIAS", "1") != "0"    # A/B knob: 0 = bias gradients by separate column-sum launches
 # fusion-layer GELU: fc1's forward epilogue stores gelu'(u) (it shares the erf evaluation's exponential) where it used to store u, and
 # fc2's dgrad epilogue multiplies by it instead of evaluating erf + exp per element (A/B knob: 0 = store u, evaluate in the backward)
+# 1 (opt-in): conv2's dgrad epilogue does the statistics pass of bn1's backward in the 8 residual blocks (msc_conv2d_dgrad_bnstat).  Built for
+# the round-2 review (item 3a), correct — and +0.03 ms in the step (profiles/r3_bn_stat_fuse_ab.txt): the heavier epilogue costs the dgrad
+# more than the 8 reduction launches it removes returned
+_BN_STAT_FUSE = os.environ.get("MSC_BN_STAT_FUSE", "0") != "0"
 _GELU_DSAVE = os.environ.get("MSC_GELU_DSAVE", "1") != "0"
 _GELU_FWD, _GELU_BWD = (L.ACT_GELU_DSAVE, L.ACT_MUL_REF) if _GELU_DSAVE else (L.ACT_GELU, L.ACT_GELU)
 
 
 def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: ParamRef, beta: ParamRef, stride, pad,
-                relu, want_dres, need_dx, dx_res=None, had_res=False, dx_relu_ref=None):
+                relu, want_dres, need_dx, dx_res=None, had_res=False, dx_relu_ref=None, dy_partials=None, x_bn=None):
     """-> (dx or None, dres or None).  dx_res: extra gradient w.r.t. x added inside the dgrad epilogue.
     dx_relu_ref: x itself when x is the output of a ReLU whose backward belongs to the PRODUCER of x: applied in the dgrad epilogue.
     stats: [4,C] mean, rstd, scale, shift of the forward.  had_res: the forward added a residual before the ReLU (the mask
-    then has to come from y; otherwise it is rebuilt from y_raw*scale+shift and y is not read)."""
+    then has to come from y; otherwise it is rebuilt from y_raw*scale+shift and y is not read).
+    x_bn = (x_raw, x_stats): x is the output of a BatchNorm + ReLU (no residual) over x_raw — this layer's dgrad epilogue then also does
+    the statistics pass of THAT BatchNorm's backward; the partial sums come back as a third result (partial, rows) for the caller to hand
+    to the producer's conv_bn_bwd as dy_partials (which then runs no reduction of its own)."""
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = conv.shape
     M = y_raw.numel() // Cout
@@ -70,8 +77,14 @@ def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: Para
     dres = rt.empty_like(y_raw) if want_dres else None
     ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
     xmask = relu and not had_res and _MASK_FROM_X
-    rt.call("msc_bn_bwd", dy, y_raw, y, stats[0], stats[1], gamma.p, stats[2] if xmask else None, stats[3] if xmask else None,
-            d_raw, dres, gamma.g, beta.g, ws, M, Cout, int(relu), rt.accumulate, rt.dt)
+    if dy_partials is not None:
+        assert xmask and not want_dres
+        part, nblk = dy_partials
+        rt.call("msc_bn_bwd_from_partials", dy, y_raw, stats[0], stats[1], gamma.p, stats[2], stats[3], part, nblk, d_raw, gamma.g, beta.g, ws,
+                M, Cout, rt.accumulate, rt.dt)
+    else:
+        rt.call("msc_bn_bwd", dy, y_raw, y, stats[0], stats[1], gamma.p, stats[2] if xmask else None, stats[3] if xmask else None,
+                d_raw, dres, gamma.g, beta.g, ws, M, Cout, int(relu), rt.accumulate, rt.dt)
     wsb = L.query("msc_wgrad_workspace_bytes", Cout, KH * KW * Cin, M)
     wsw = rt.workspace("wgrad", wsb, per_stream=False)     # only the side stream touches it
     def wgrad():
@@ -90,8 +103,14 @@ def conv_bn_bwd(rt: Runtime, dy, x, y_raw, y, stats, conv: ParamRef, gamma: Para
         dx = rt.empty_like(x)
         wsd = L.query("msc_conv2d_splitk_workspace_bytes", B * H * W, Cin, KH * KW * Cout, rt.dt) if stride == 1 else 0
         ws = rt.workspace("conv_splitk", wsd) if wsd else None
+        if x_bn is not None:
+            assert dx_relu_ref is None and stride == 1
+            nblk = L.query("msc_conv2d_dgrad_stat_rows", B * H * W, Cin, rt.dt)
+            part = rt.f32(nblk * 2 * Cin)
+            rt.call("msc_conv2d_dgrad_bnstat", d_raw, conv.t, dx_res, dx, x_bn[0], x_bn[1], part, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsd, rt.dt)
+            return dx, dres, (part, nblk)
         rt.call("msc_conv2d_dgrad", d_raw, conv.t, dx_res, dx_relu_ref, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, wsd, rt.dt)
-    return dx, dres
+    return (dx, dres, None) if x_bn is not None else (dx, dres)
 
 
 class ConvBNAct(torch.autograd.Function):
@@ -207,21 +226,27 @@ class BasicBlockFn(torch.autograd.Function):
         sv = ctx.saved_tensors
         x, o1_raw, o1, st1, o2_raw, y, st2 = sv[:7]
         dy = dy.contiguous()
+        # conv2's dgrad produces dy of bn1 (+ ReLU, no residual): its epilogue does bn1's backward statistics pass (MSC_BN_STAT_FUSE=0: a
+        # reduction kernel of bn1's own re-reads do1 and o1_raw)
+        fuse = (o1_raw, st1) if (_BN_STAT_FUSE and _MASK_FROM_X) else None
+        part1 = None
         if dy_masked:
             # the consumer's dgrad epilogue already applied this block's output ReLU: BatchNorm backward without a mask, identity = dy
-            do1, _ = conv_bn_bwd(rt, dy, o1, o2_raw, None, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, False, False, True)
-            didt = dy
+            r = conv_bn_bwd(rt, dy, o1, o2_raw, None, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, False, False, True, x_bn=fuse)
+            do1, didt = r[0], dy
         else:
             # conv2/bn2: dres = gradient of the identity branch (post-ReLU mask, which needs y: the residual was added before the ReLU)
-            do1, didt = conv_bn_bwd(rt, dy, o1, o2_raw, y, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True, True, True,
-                                    had_res=True)
+            r = conv_bn_bwd(rt, dy, o1, o2_raw, y, st2, p["conv2"], p["bn2g"], p["bn2b"], 1, 1, True, True, True, had_res=True, x_bn=fuse)
+            do1, didt = r[0], r[1]
+        if fuse is not None:
+            part1 = r[2]
         if has_ds:
             idt_raw, std = sv[7:]
             dx_id, _ = conv_bn_bwd(rt, didt, x, idt_raw, None, std, p["dconv"], p["dbng"], p["dbnb"], stride, 0, False, False, True)
         else:
             dx_id = didt
         dx, _ = conv_bn_bwd(rt, do1, x, o1_raw, o1, st1, p["conv1"], p["bn1g"], p["bn1b"], stride, 1, True, False, True, dx_res=dx_id,
-                            dx_relu_ref=x if mask_in else None)
+                            dx_relu_ref=x if mask_in else None, dy_partials=part1)
         return dx, None, None, None, None, None
 
 

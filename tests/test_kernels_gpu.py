@@ -384,6 +384,61 @@ def test_conv_dgrad_relu_ref(rts, dtype, case):
     assert (masked[0, 0, 0, :4] == 0).all() and masked.abs().max() > 0
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(4, 28, 28, 64, 64, 3, 1, 1), (3, 7, 7, 256, 512, 3, 1, 1), (2, 14, 14, 128, 128, 3, 1, 1), (2, 9, 9, 24, 64, 3, 1, 1)])
+def test_conv_dgrad_bn_statistics(rts, dtype, case):
+    """msc_conv2d_dgrad_bnstat: the same dx as msc_conv2d_dgrad, bit for bit, plus per-row-block sums of dz and dz*xhat for the BatchNorm + ReLU
+    that produced the layer's input — msc_bn_bwd_from_partials then gives the dx / dgamma / dbeta of msc_bn_bwd on that dx (same terms, another
+    summation order).  Un-split epilogue (128x64 and 128x128 tiles, a ragged 24-channel case) and the split-K finish (7x7x256)."""
+    from multimodal_sc_amd import lib as L
+    rt = rts[dtype]
+    B, H, W, Cin, Cout, K, s, p = case
+    w = rnd(Cout, K, K, Cin, seed=1, scale=0.1)
+    Wp = FakeParam(rt, w, "conv")
+    dy, rs = dev(rnd(B, H, W, Cout, seed=2), rt), dev(rnd(B, H, W, Cin, seed=3), rt)
+    x_raw = dev(rnd(B, H, W, Cin, seed=4) * 1.5 + 0.3, rt)                    # the input of the BatchNorm in front of this conv
+    M = B * H * W
+    xf = x_raw.float().reshape(M, Cin)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    gamma = torch.linspace(0.5, 1.5, Cin, device=rt.device)
+    beta = torch.linspace(-0.3, 0.3, Cin, device=rt.device)
+    scale = gamma * rstd
+    stats = torch.stack([mean, rstd, scale, beta - mean * scale]).contiguous()
+    wsb = L.query("msc_conv2d_splitk_workspace_bytes", M, Cin, K * K * Cout, rt.dt)
+    ws = torch.empty(max(wsb // 4, 1), device=rt.device) if wsb else None
+    plain = torch.empty(B, H, W, Cin, device=rt.device, dtype=rt.tdtype)
+    fused = torch.full_like(plain, float("nan"))
+    nblk = L.query("msc_conv2d_dgrad_stat_rows", M, Cin, rt.dt)
+    part = torch.full((nblk, 2, Cin), float("nan"), device=rt.device)
+    rt.call("msc_conv2d_dgrad", dy, Wp.t, rs, None, plain, B, H, W, Cin, Cout, K, K, s, p, ws, wsb, rt.dt)
+    rt.call("msc_conv2d_dgrad_bnstat", dy, Wp.t, rs, fused, x_raw, stats, part, B, H, W, Cin, Cout, K, K, s, p, ws, wsb, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, fused)
+    assert torch.isfinite(part).all()
+    # the sums themselves against fp64 of the stored values
+    mask = (xf * stats[2] + stats[3]) > 0
+    dz = torch.where(mask, plain.float().reshape(M, Cin), torch.zeros((), device=rt.device)).double()
+    xhat = ((xf - mean) * rstd).double()
+    check("sum dz", part[:, 0].double().sum(0), dz.sum(0), 2e-5 if dtype == "f32" else 2e-4)
+    check("sum dz xhat", part[:, 1].double().sum(0), (dz * xhat).sum(0), 2e-5 if dtype == "f32" else 2e-4)
+    # and through the BatchNorm backward
+    outs = []
+    for mode in (0, 1):
+        dx = torch.full_like(plain, float("nan"))
+        dg, db = torch.zeros(Cin, device=rt.device), torch.zeros(Cin, device=rt.device)
+        wsn = torch.empty(L.query("msc_bn_bwd_workspace_bytes", Cin) // 4, device=rt.device)
+        if mode == 0:
+            rt.call("msc_bn_bwd", plain, x_raw, None, stats[0], stats[1], gamma, stats[2], stats[3], dx, None, dg, db, wsn, M, Cin, 1, 0, rt.dt)
+        else:
+            rt.call("msc_bn_bwd_from_partials", plain, x_raw, stats[0], stats[1], gamma, stats[2], stats[3], part, nblk, dx, dg, db, wsn, M, Cin, 0, rt.dt)
+        outs.append((dx.float().clone(), dg.clone(), db.clone()))
+    t = 1e-5 if dtype == "f32" else 1e-2
+    check("dx", outs[1][0], outs[0][0], t)
+    check("dgamma", outs[1][1], outs[0][1], 1e-4)
+    check("dbeta", outs[1][2], outs[0][2], 1e-4)
+
+
 # ------------------------------------------------------------------------------------------------ conv + BN
 CONV_CASES = [  # B,H,W,Cin,Cout,K,stride,pad
     (2, 16, 16, 8, 64, 7, 2, 3),
@@ -560,6 +615,35 @@ def test_block_chain_premasked_gradient_is_bitwise_the_same(rts, dtype, shape):
     assert res[0][1].abs().max() > 0
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_block_with_fused_bn_statistics(rts, dtype, monkeypatch):
+    """A BasicBlock whose conv2 dgrad epilogue does bn1's backward statistics pass (MSC_BN_STAT_FUSE=1, opt-in): every gradient equals the
+    default path's within the summation-order difference of the two per-channel sums."""
+    from multimodal_sc_amd import functional as F
+    rt = rts[dtype]
+    B, H, C = 3, 14, 64
+    x, dy = rnd(B, H, H, C, seed=1), rnd(B, H, H, C, seed=7)
+    ws = {"conv1": rnd(C, 3, 3, C, seed=100, scale=0.05), "conv2": rnd(C, 3, 3, C, seed=101, scale=0.05)}
+    vec = {k: (1 + 0.1 * rnd(C, seed=110 + i)) if k.endswith("g") else 0.1 * rnd(C, seed=120 + i) for i, k in enumerate(["bn1g", "bn1b", "bn2g", "bn2b"])}
+    res = []
+    for fuse in (False, True):
+        monkeypatch.setattr(F, "_BN_STAT_FUSE", fuse)
+        p = {k: FakeParam(rt, v, "conv") for k, v in ws.items()}
+        p.update({k: FakeParam(rt, v, "vec") for k, v in vec.items()})
+        xd = dev(x, rt).requires_grad_()
+        y = F.BasicBlockFn.apply(xd, rt, p, 1)
+        y.backward(dev(dy, rt))
+        torch.cuda.synchronize()
+        rt.join_side()
+        torch.cuda.synchronize()
+        res.append((xd.grad.float().clone(), {k: pp.g.clone() for k, pp in p.items()}))
+    t = 1e-5 if dtype == "f32" else 2e-2
+    check("dx", res[1][0], res[0][0], t)
+    for k in res[0][1]:
+        check(k, res[1][1][k], res[0][1][k], 1e-4 if dtype == "f32" else 2e-2)
+    assert res[0][0].abs().max() > 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

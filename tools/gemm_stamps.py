@@ -12,6 +12,8 @@ rt = Runtime("bf16", "cuda:0")
 dll = L.lib.load()
 dll.msc_debug_gemm_stamps.restype = ctypes.c_int
 dll.msc_debug_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dll.msc_debug_gemm_stamps_ep.restype = ctypes.c_int
+dll.msc_debug_gemm_stamps_ep.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = rt.device
 rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 B = 64
@@ -40,3 +42,9 @@ for name in (sys.argv[1:] or ["qkv", "fc2", "big"]):
               f"epilogue {med(lambda r: r[4]):.0f} tiles {med(lambda r: r[6]):.0f} steps {med(lambda r: r[7]):.0f} "
               f"-> per step {med(lambda r: r[3] / max(r[7], 1)):.0f} cyc (wait {med(lambda r: r[2] / max(r[7], 1)):.0f}), "
               f"start spread {max(r[0] for r in rows) - t0}")
+        if bm != 256:
+            assert dll.msc_debug_gemm_stamps_ep(buf, nwg) == 0
+            ep = [buf[i * 8:(i + 1) * 8] for i in range(nwg)]
+            m2 = lambda i: statistics.median(r[i] for r in ep)
+            print(f"    epilogue of wave 0: barrier after the K loop {m2(0):.0f} | statistics {m2(1):.0f} | accumulators -> slab + barrier {m2(2):.0f} | "
+                  f"slab -> stores issued {m2(3):.0f} | barrier between passes (waits for the stores) {m2(4):.0f} | tail {m2(5):.0f}")
