@@ -371,6 +371,11 @@ __global__ void bn_pool_bwd_apply_kernel(const T* __restrict__ dpool, const uint
 // ---------------------------------------------------------------- LayerNorm
 // one wave per row, the row lives in registers (D <= 64*LN_MAXC); D % (64*VEC) == 0
 #define LN_MAXC 16
+// LN_FWD_ROWS consecutive rows per wave, all their loads issued before the first reduction: one row per wave left 16 bytes per lane in
+// flight (tools/ln_bench.py, 19584 x 512 bf16, cache-warm: 1 row 9.5 us, 2 rows 8.9, 4 rows 10.2, 8 rows 12.1)
+#ifndef LN_FWD_ROWS
+#define LN_FWD_ROWS 2
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -378,40 +383,71 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      int D, float eps) {
   constexpr int VEC = msc_traits<T>::VEC;
   constexpr int MAXIT = LN_MAXC / VEC;
+  constexpr int R = LN_FWD_ROWS;
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
   const int nit = D / (64 * VEC);
-  vecf<T> v[MAXIT];
-  float s = 0.f;
+  if (nit == 1) {       // D = 64 * VEC (the path's 512 in bf16): the R rows' loads in flight together, gamma / beta once
+    vecf<T> v[R];
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-    if (it < nit) {
-      v[it].load(x + row * D + (it * 64 + lane) * VEC);
+    for (int r = 0; r < R; ++r)
+      if (row0 + r < rows) v[r].load(x + (row0 + r) * D + lane * VEC);
+    float g[VEC], b[VEC];
+    ldc<VEC>(gamma + lane * VEC, g);
+    ldc<VEC>(beta + lane * VEC, b);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) s += v[it].v[j];
+    for (int r = 0; r < R; ++r) {
+      if (row0 + r >= rows) break;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s += v[r].v[j];
+      const float mu = wave_sum(s) / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { const float d = v[r].v[j] - mu; q += d * d; }
+      const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[r].v[j] = (v[r].v[j] - mu) * rs * g[j] + b[j];
+      v[r].store(y + (row0 + r) * D + lane * VEC);
+      if (lane == 0) { mean[row0 + r] = mu; rstd[row0 + r] = rs; }
     }
-  const float mu = wave_sum(s) / (float)D;
-  float q = 0.f;
+    return;
+  }
+  for (int r = 0; r < R; ++r) {
+    const long row = row0 + r;
+    if (row >= rows) break;
+    vecf<T> v[MAXIT];
+    float s = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-    if (it < nit) {
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        v[it].load(x + row * D + (it * 64 + lane) * VEC);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { const float d = v[it].v[j] - mu; q += d * d; }
-    }
-  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        for (int j = 0; j < VEC; ++j) s += v[it].v[j];
+      }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-    if (it < nit) {
-      const int c0 = (it * 64 + lane) * VEC;
-      float g[VEC], b[VEC];
-      ldc<VEC>(gamma + c0, g);
-      ldc<VEC>(beta + c0, b);
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) v[it].v[j] = (v[it].v[j] - mu) * rs * g[j] + b[j];
-      v[it].store(y + row * D + c0);
-    }
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        for (int j = 0; j < VEC; ++j) { const float d = v[it].v[j] - mu; q += d * d; }
+      }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int c0 = (it * 64 + lane) * VEC;
+        float g[VEC], b[VEC];
+        ldc<VEC>(gamma + c0, g);
+        ldc<VEC>(beta + c0, b);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[it].v[j] = (v[it].v[j] - mu) * rs * g[j] + b[j];
+        v[it].store(y + row * D + c0);
+      }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
 }
 
 // block = 4 waves, LN_ROWS_PER_BLOCK rows (each wave takes every 4th); each lane owns D/64 columns
@@ -759,7 +795,7 @@ extern "C" int msc_layernorm_fwd(const void* x, const float* gamma, const float*
                                  float* rstd, int64_t rows, int D, float eps, int dtype, void* stream) {
   MSC_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0 && D <= 1024);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)cdiv(rows, 4);
+  const unsigned grid = (unsigned)cdiv(rows, 4 * LN_FWD_ROWS);
   if (dtype == MSC_F32) {
     MSC_CHECK_ARG(D % 256 == 0);
     hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y,
