@@ -124,10 +124,17 @@ static inline int plan_split(long rows_out, long cols_out, long reduce_len) {
     if (target < 1) target = 640;
   }
   long want = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
-  long cap = reduce_len / 1024;
+  // A slice is a SERIAL K loop of one workgroup.  Outputs of one to four tiles (1x1 downsample convolutions: 16 workgroups x 25 steps ran
+  // 50 us for 0.8 GFLOP; the stem: 256 workgroups x 98 steps, 150 us, the last kernel of the backward) are latency-bound on that
+  // loop and their slabs are small: shorter slices (>= 256 reduction rows) and up to 512 of them.  MSC_WGRAD_SMALL=0: the old limits.
+  static const int small_on = getenv("MSC_WGRAD_SMALL") ? atoi(getenv("MSC_WGRAD_SMALL")) : 1;     // A/B knob
+  static const long small_max = getenv("MSC_WGRAD_SMALL_MAX") ? atol(getenv("MSC_WGRAD_SMALL_MAX")) : 512;   // A/B knob
+  const bool small = small_on && tiles <= 4;
+  long cap = reduce_len / (small_on && tiles <= 8 ? 256 : 1024);
   if (want > cap) want = cap;
   if (want < 1) want = 1;
-  if (want > 128) want = 128;
+  const long maxw = small ? small_max / tiles : 128;
+  if (want > maxw) want = maxw;
   // multiples of 8 let the kernel pin each K slice to one XCD (xcd_split)
   static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;   // A/B knob
   if (xs && want >= 6) {

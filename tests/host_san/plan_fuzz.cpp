@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
       const int kt2 = (rnd() & 1) ? KT : KT / 2;
       const mscplan::WgradSplit w = mscplan::wgrad_split(M2, N2, R, kt2);
       const long nk = mscplan::cdivl(R, kt2);
-      CHECK(w.ns >= 1 && w.ns <= 128);
+      CHECK(w.ns >= 1 && w.ns <= 520);      // (128, or 512 / tiles for outputs of at most four tiles)
       CHECK((long)w.ns * w.tps >= nk && (long)(w.ns - 1) * w.tps < nk);
       CHECK(w.ws_bytes >= (int64_t)w.ns * M2 * (N2 + 1) * 4);                         // weight slabs + bias-gradient rows
       CHECK(mscplan::wgrad_workspace_bytes(M2, N2, R) == w.ws_bytes);                 // msc_wgrad_workspace_bytes
