@@ -186,6 +186,7 @@ def host_inputs_leg(args, cfg, model, trainer, dev_batch, ms_device_resident):
     st = FrameStager(model.rt, src, B, extra_fn=lambda k: ppo)
 
     own = [None]
+    direct = os.environ.get("MSC_BENCH_OWN_INPUTS", "1") != "0"     # (0: A/B knob — decode into the stager's tensor, step() copies it)
 
     def step():
         b = st.next(image_out=own[0]["image"] if own[0] is not None else None)      # camera bytes decoded straight into the step's input
@@ -193,7 +194,7 @@ def host_inputs_leg(args, cfg, model, trainer, dev_batch, ms_device_resident):
         feed = {k: b[k] for k in ("image", "points", "state") if k in b}        # same keys as the device-resident batch
         feed.update(snr_db=dev_batch["snr_db"], noise=None, fading=None, ppo=dict(b["extra"]))
         terms = trainer.step(feed)
-        if own[0] is None:
+        if own[0] is None and direct:
             own[0] = trainer.input_buffers(feed)
         return terms
 

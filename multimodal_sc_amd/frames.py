@@ -137,8 +137,13 @@ class FrameStager:
             L.call("msc_event_synchronize", self.events[slot])      # the slot's previous copy must have left the pinned buffer
             idx = np.asarray(self.index_fn(k))
             pn = self.pinned_np[slot]
+            i0 = int(idx[0])
+            run = len(idx) > 0 and i0 + len(idx) <= self.n and bool(np.all(np.diff(idx) == 1))
             for key in self.keys:
-                np.take(self.src[key], idx, axis=0, out=pn[key])
+                if run:          # a window of consecutive frames: one block copy (a gather of 26 MB per batch is what paces this thread)
+                    np.copyto(pn[key], self.src[key][i0:i0 + len(idx)])
+                else:
+                    np.take(self.src[key], idx, axis=0, out=pn[key])
             if self.extra_fn is not None:
                 for kk, v in self.extra_fn(k).items():
                     np.copyto(pn["x_" + kk], v)
