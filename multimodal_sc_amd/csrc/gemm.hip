@@ -1194,13 +1194,16 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
 #endif
   if (zs > 65535) return MSC_ERR_UNSUPPORTED;
 #ifdef GEMM_NP256_BUILD
+#ifndef GEMM_NP256_THREADS
+#define GEMM_NP256_THREADS 512      // 256: four waves with 128x64 wave tiles (the wave-tile shape of the vendor library's kernels on these shapes)
+#endif
   // one-tile-per-workgroup 256x128 (8 waves, wave tile 64x64, 64-byte K steps x 3 stages = 72 KB: TWO workgroups per CU):
   // 0.75x the staged bytes and DMA instructions per FLOP of the 128x128 tile.  Experiment build only (MSC_GEMM_NP256=1).
   if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
     const char* e = getenv("MSC_GEMM_NP256");
     if (e && atoi(e) && p.M >= 256 && p.N >= 128 && zs == 1 && p.nsplit == 1 && !p.stats && !p.colsum && !(AMODE == OPM_CONV_DGRAD && p.cls)) {
       dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, 128)), 1, 1);
-      hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, 64, 3, false, 512>), grid, dim3(512), 0, st, q);
+      hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, 64, 3, false, GEMM_NP256_THREADS>), grid, dim3(GEMM_NP256_THREADS), 0, st, q);
       return msc_launch_status();
     }
   }
