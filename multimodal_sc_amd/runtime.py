@@ -233,6 +233,9 @@ class Runtime:
             self._side_keep.clear()
 
 
+_TR_LO_SIDE = os.environ.get("MSC_TR_LO_SIDE", "1") != "0"
+
+
 class ParamStore:
     ALIGN = 64
 
@@ -332,7 +335,9 @@ class ParamStore:
         rt.call("msc_adam_step", self.P[:split], self.G[:split], self.M[:split], self.V[:split], shadow(0, split), split, *hp)
         t, blk = tabs["lo"]
         if t is not None:
-            rt.call("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
+            # the transposed copies feed the dgrads only: off the step boundary's critical path, onto the side stream (which waits for the
+            # update above; the next forward joins the side stream before the fusion, long before the first dgrad).  MSC_TR_LO_SIDE=0: main
+            (rt.call_side if _TR_LO_SIDE else rt.call)("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
         self._refresh_stem()
         n_hi = self.total - split
         rt.call_side("msc_adam_step", self.P[split:], self.G[split:], self.M[split:], self.V[split:], shadow(split, self.total), n_hi, *hp)
