@@ -81,6 +81,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #ifndef GEMM_WG_STAGES
 #define GEMM_WG_STAGES 3    // ring depth of the gathered conv weight-gradient kernels (64-byte K steps)
 #endif
+#ifndef GEMM_FRAG_AHEAD
+#define GEMM_FRAG_AHEAD 0   // 1 (A/B builds): all fragment reads of a K step issued before its first MFMA.  Measured (profiles/r3_gemm_frag_ahead.txt): the
+                            // same time on every shape and in the step — the latency in front of each MFMA was already covered by the other waves of
+                            // the SIMD; the K loop is bound by LDS THROUGHPUT.  Off: it costs 18 registers for nothing.
+#endif
 #ifndef GEMM_NT_STORE
 #define GEMM_NT_STORE 1     // output tiles leave with non-temporal stores: written once, never re-read by this launch, so they
 #endif                      // should not evict the operand panels other tiles of the launch still re-read from L2 (-3 % on the linears)
@@ -660,7 +665,29 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
       }
       const char* As = smem + cslot * STAGE_BYTES;
       const char* Bs = As + A_BYTES;
-      if constexpr (sizeof(T) == 2) {
+      // (experiment, off) k-major operands of the one-tile-per-workgroup kernels: ALL fragment reads of the K step issued before its first MFMA (the
+      // compiler, left alone, keeps one read ahead of each MFMA — 12 fragment registers, an LDS latency in front of every product);
+      // the MFMAs then wait with counted lgkmcnt for the fragments in the order they arrive
+      constexpr bool FRAG_AHEAD = GEMM_FRAG_AHEAD && sizeof(T) == 2 && LA::KM && LB::KM && !PERSIST && !ROWSUM && (MI + NI) * (KT / 16) * 4 <= 64;
+      if constexpr (FRAG_AHEAD) {
+        constexpr int NKS2 = KT / 16;
+        mfma_bf16x8_t fa[NKS2][MI], fb[NKS2][NI];
+#pragma unroll
+        for (int ks = 0; ks < NKS2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[ks][i] = *reinterpret_cast<const mfma_bf16x8_t*>(As + lds_chunk_off<KB>(wm * WM + i * 32 + lr, 2 * ks + lh));
+#pragma unroll
+          for (int j = 0; j < NI; ++j) fb[ks][j] = *reinterpret_cast<const mfma_bf16x8_t*>(Bs + lds_chunk_off<KB>(wn * WN + j * 32 + lr, 2 * ks + lh));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NKS2; ++ks)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (sizeof(T) == 2) {
         // lane geometry of the transposed read (mn-major images): 16-lane group g, row q / column quad pq inside it
         const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
 #pragma unroll
