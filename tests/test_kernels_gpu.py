@@ -1011,9 +1011,10 @@ def test_ppo_hand_computed(rts):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_recon_loss_psnr(rts, dtype):
+@pytest.mark.parametrize("G,P", [(2, 32), (3, 12)])      # 8-pixel vector path / element-wise path (P % 8 != 0)
+def test_recon_loss_psnr(rts, dtype, G, P):
     rt = rts[dtype]
-    B, G, P = 3, 2, 32
+    B = 3
     img = torch.rand(B, 3, G * P, G * P, generator=torch.Generator().manual_seed(1))
     pat = torch.rand(B * G * G, P * P * 3, generator=torch.Generator().manual_seed(2))
     pq = q(pat, dtype)
