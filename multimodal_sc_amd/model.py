@@ -358,7 +358,9 @@ class MultimodalSC:
         else:                      # hipGraph replay: the number must live on the device
             rx = F.ChannelFn.apply(sym, rt, snr_db, noise, fading, mode, key, 0, self.draw_dev)
             if inkernel:
-                rt.call("msc_counter_add", self.draw_dev, 1)
+                # off the latency-bound codec stretch: the side stream waits for the channel kernel above, and every forward joins the side
+                # stream (before the fusion) ahead of its own channel kernel
+                rt.call_side("msc_counter_add", self.draw_dev, 1)
         z = self._mlp2(rx, "semantic_decoder.fc1", L.ACT_RELU, "semantic_decoder.fc2", L.ACT_NONE)
         # policy/value head + reconstruction head: one autograd node (z has two consumers; functional.HeadsFn sums their
         # gradients inside a dgrad epilogue instead of an add kernel)
