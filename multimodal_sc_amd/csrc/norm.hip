@@ -671,6 +671,17 @@ extern "C" int msc_bn_apply(const void* x, const float* scale, const float* shif
 
 extern "C" int64_t msc_bn_bwd_workspace_bytes(int C) { return (int64_t)(BN_MAX_BLOCKS + 1) * 2 * C * 4; }
 
+// Rows per block of the BatchNorm-backward reduction.  A block has nty = 256 / (C / VEC) row lanes; its threads walk their rows one after the
+// other, so with 128 rows per block a 512-channel layer (4 row lanes) made 32 dependent load rounds per thread — the reduction of a 3 MB
+// tensor took as long as that of a 50 MB one (the launch was 25 blocks).  At most BN_ROWS_PER_LANE rows per lane, 32..128 rows per block.
+#ifndef BN_ROWS_PER_LANE
+#define BN_ROWS_PER_LANE 8
+#endif
+static inline int bn_reduce_rows_per_block(int nty) {
+  int r = BN_ROWS_PER_LANE * nty;
+  return r < 32 ? 32 : (r > 128 ? 128 : r);
+}
+
 // partial_in / nblk_in: the statistics pass was done by the kernel that produced dy (msc_conv2d_dgrad_bnstat): [nblk_in][2][C] row-block sums
 template <typename T>
 static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
@@ -684,7 +695,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* m
   if (partial_in) {
     launch_fin_sums(partial_in, nblk_in, C, sums, sums + C, dbeta, dgamma, accumulate, st);
   } else {
-    int nblk = cdiv(rows, 128);
+    int nblk = cdiv(rows, bn_reduce_rows_per_block(nty));
     if (nblk > BN_MAX_BLOCKS) nblk = BN_MAX_BLOCKS;
     const int rpb = cdiv(rows, nblk);
     nblk = cdiv(rows, rpb);
@@ -759,7 +770,7 @@ static int bn_pool_bwd_t(const void* dpool, const uint8_t* idx, const void* xsel
   // statistics pass on the POOLED size: sum over windows of dpool*[relu'] and dpool*[relu']*xhat at the window's arg-max (xsel) equals
   // the sum over pixels of the gathered gradient — the generic BatchNorm-backward reduction with dy = dpool, x = xsel
   const long prow = (long)B * g.Ho * g.Wo;
-  int nblk = cdiv(prow, 128);
+  int nblk = cdiv(prow, bn_reduce_rows_per_block(nty));
   if (nblk > BN_MAX_BLOCKS) nblk = BN_MAX_BLOCKS;
   const int rpb = cdiv(prow, nblk);
   nblk = cdiv(prow, rpb);
