@@ -198,7 +198,7 @@ def host_inputs_leg(args, cfg, model, trainer, dev_batch, ms_device_resident):
             own[0] = trainer.input_buffers(feed)
         return terms
 
-    for _ in range(max(args.warmup, 4)):
+    for _ in range(max(args.warmup, nb + 2)):       # one whole pass over the source ring first (first touch of its pages is not the steady state)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
