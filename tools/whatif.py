@@ -24,8 +24,14 @@ orig = L.call
 skip = [None]
 
 
+OPT = re.compile("msc_adam_step|msc_permute3_cast_batched|msc_stem_weight_s2d")
+skip_opt = [False]
+
+
 def call(name, *a):
     if skip[0] is not None and skip[0].search(name):
+        return 0
+    if skip_opt[0] and OPT.search(name):      # no optimizer update while something upstream is skipped: garbage gradients must not reach the parameters
         return 0
     return orig(name, *a)
 
@@ -44,13 +50,34 @@ def timed(n=30):
 
 for _ in range(5):
     tr.step(b)
-def measure(rx):
-    skip[0] = re.compile(rx) if rx else None
+torch.cuda.synchronize()
+ps = m.params
+snap = (ps.P.clone(), ps.M.clone(), ps.V.clone())
+
+
+def restore():
+    # lr = 0 does not protect the parameters from a skipped kernel's garbage: 0 * NaN = NaN, and a step on NaN data draws less power and runs at a
+    # higher clock (the baseline after a skipped dgrad was 0.45 ms "faster") — every measurement starts from the same finite state
+    torch.cuda.synchronize()
+    m.rt.join_side()
+    torch.cuda.synchronize()
+    ps.P.copy_(snap[0]); ps.M.copy_(snap[1]); ps.V.copy_(snap[2])
+    ps.refresh_compute_copies()
+    torch.cuda.synchronize()
+
+
+def measure(rx, no_opt):
+    restore()
+    skip[0] = None
+    skip_opt[0] = no_opt
     tr.step(b)
+    skip[0] = re.compile(rx) if rx else None
     return statistics.median([timed() for _ in range(3)])
 
 
+print("# baseline and variant of a row both run WITHOUT the optimizer update (parameters stay finite: NaN data draws less power and clocks higher), except the row that skips the update itself")
 for rx in sys.argv[1:]:
-    b0 = measure(None)      # a fresh baseline before every variant: the box drifts by several 0.1 ms over a minute
-    v = measure(rx)
+    targets_opt = bool(OPT.search(rx.split("|")[0])) or "adam" in rx
+    b0 = measure(None, not targets_opt)      # a fresh baseline before every variant: the box drifts by several 0.1 ms over a minute
+    v = measure(rx, not targets_opt)
     print(f"skip {rx:44s} {v:7.3f} ms/step   baseline {b0:7.3f}   delta {v - b0:+.3f}")
