@@ -15,6 +15,9 @@ Rank 0 prints ONE JSON line with the contract fields plus:
                  FLOPs per step / summed duration of its launches per step, measured with HIP events on the launch
                  stream in an instrumented step, against the dense bf16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline — the build-authored PyTorch-CPU oracle timed on this box's host cores on a bounded sample.
+  parity       — (N = 1) decoder-PSNR / logit / action deltas of the benchmarked model against the oracle on the same parameters and
+                 frames with explicit noise: the second half of BASELINE.json's metric.
+  alt_geometry — the same step at 32 frames per GPU (configs[3]'s shard size), labelled, beside the 64-per-GPU `value`.
 """
 import argparse
 import json
@@ -165,6 +168,39 @@ def cpu_baseline(cfg_name, seconds_budget=80.0):
             "step_s_median": med, "step_s_min": min(times), "step_s_max": max(times),
             "sample": f"oracle/model.py fwd+bwd, config {cfg_name}, batch {B}: {n_warm} warm-up + {n_timed} timed steps, median, fp32, "
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} host cpus, no optimizer step"}
+
+
+def parity_leg(cfg_name, model, frames=32):
+    """The second half of BASELINE.json's metric ("+ decoder-PSNR parity vs CPU ref"), in the mode and on the model that was just
+    benchmarked: the oracle (checker only; never on the timed path) receives the benchmarked model's CURRENT parameters, both run one
+    forward on the same `frames` synthetic frames with EXPLICIT channel noise, and the line reports decoder-PSNR delta, max |logit|
+    delta and whether the arg-max actions agree (all frames / frames whose oracle top-2 margin exceeds 0.1)."""
+    import torch
+    from oracle import model as O
+    ocfg = O.named_config(cfg_name)
+    om = O.build_oracle(ocfg, seed=0)
+    missing = om.load_state_dict(model.export_state_dict(), strict=False)
+    assert not missing.unexpected_keys and all(k.rsplit(".", 1)[-1] in ("running_mean", "running_var", "num_batches_tracked")
+                                               for k in missing.missing_keys), missing      # (BatchNorm runs on batch statistics on both sides)
+    batch = O.synthetic_batch(ocfg, frames, seed=4242)
+    with torch.no_grad():
+        oout = om(batch["image"], batch.get("points"), batch.get("state"), batch["snr_db"], batch["noise"], batch["fading"])
+    d = model.rt.device
+    g = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items() if k != "ppo"}
+    with torch.no_grad():
+        out = model(g["image"], g.get("points"), g.get("state"), g["snr_db"], g["noise"], g["fading"])
+        logits, _ = model.logits_value(out)
+        rec = model.recon_image(out)
+    torch.cuda.synchronize()
+    psnr_g = O.psnr(rec.float().cpu(), batch["image"]).mean().item()
+    psnr_o = O.psnr(oout["recon"], batch["image"]).mean().item()
+    ga, oa = model.select_action(out).cpu(), O.select_action(oout["logits"])
+    top2 = oout["logits"].topk(2, -1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 0.1
+    return {"frames": frames, "noise": "explicit (same tensors on both sides)", "psnr_db_gpu": psnr_g, "psnr_db_oracle": psnr_o,
+            "psnr_abs_db": abs(psnr_g - psnr_o), "logit_max_abs": (logits.float().cpu() - oout["logits"]).abs().max().item(),
+            "actions_equal": bool(torch.equal(ga, oa)), "actions_equal_where_margin_gt_0p1": bool(torch.equal(ga[sure], oa[sure])),
+            "frames_with_margin_gt_0p1": int(sure.sum()), "checker": "oracle/model.py (fp32, host cores) on the benchmarked model's parameters"}
 
 
 def host_inputs_leg(args, cfg, model, trainer, dev_batch, ms_device_resident):
@@ -352,6 +388,10 @@ def main(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true",
                     help="also time the step fed from a host-resident frame source (pinned ring + H2D staging)")
+    ap.add_argument("--alt-frames-per-gpu", type=int, default=32, metavar="F",
+                    help="also time the step at F frames per GPU after the main measurement (BASELINE.json configs[3]: batch 256 sharded "
+                         "8x = 32 frames per GPU); reported as `alt_geometry`, never as `value`; 0 = skip")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity block of the JSON line")
     ap.add_argument("--selftest-ranks", action="store_true", help="launch-path self-test on gloo: no GPU, no model")
     ap.add_argument("--instrumented-only", type=int, default=0, metavar="N",
                     help="profiling aid: run ONLY N single-stream instrumented passes (every kernel alone, HIP events around it) — "
@@ -449,6 +489,31 @@ def main(argv=None):
         result["dp_schedule"] = [list(x) for x in trainer.exchange.log] if trainer.exchange is not None else "flat buckets"
         result["allreduce_alone"] = allreduce_probe(model, trainer, dist, torch)
 
+    if args.alt_frames_per_gpu and args.alt_frames_per_gpu != B:
+        # BASELINE.json configs[3] geometry (32 frames per GPU: batch 256 over 8 GPUs) beside the 64-per-GPU weak-scaling number: the
+        # same step at the other shard size, every rank, same barrier + max-over-ranks timing.  Labelled; never `value`.
+        Fa = args.alt_frames_per_gpu
+        cpu_alt = synthetic_batch(cfg, Fa, seed=2000 + rank)
+        alt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in cpu_alt.items() if k != "ppo"}
+        alt["ppo"] = {k: v.to(dev) for k, v in cpu_alt["ppo"].items()}
+        alt["noise"] = None
+        alt["fading"] = None
+        for _ in range(max(args.warmup, 4)):          # (a batch of another shape records its own launch list: 2 eager + 1 recorded step)
+            trainer.step(alt)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(alt)
+        barrier()
+        dta = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dta], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dta = float(t.item())
+        result["alt_geometry"] = {"label": f"{Fa} frames per GPU (BASELINE.json configs[3] shards batch 256 over 8 GPUs = 32 per GPU)",
+                                  "frames_per_gpu": Fa, "global_batch": Fa * world, "value": world * Fa * args.steps / dta, "unit": "frames/s",
+                                  "ms_per_step": 1e3 * dta / args.steps, "frames_per_s_per_gpu": Fa * args.steps / dta}
+
     if args.host_inputs and world == 1:
         result["host_inputs"] = host_inputs_leg(args, cfg, model, trainer, batch, result["ms_per_step"])
 
@@ -474,6 +539,8 @@ def main(argv=None):
                                                "(marker + dispatch latency of ~5 us per C-ABI call), so `achieved` is the conservative of the two"}
         result["breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 
+    if rank == 0 and world == 1 and not args.no_parity:
+        result["parity"] = parity_leg(args.config, model)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.config)
         result["gpu_over_cpu"] = result["frames_per_s_per_gpu"] / result["cpu_baseline"]["value"]

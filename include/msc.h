@@ -37,8 +37,24 @@ enum { MSC_ACT_NONE = 0, MSC_ACT_RELU = 1, MSC_ACT_GELU = 2, MSC_ACT_TANH = 3, M
        MSC_ACT_MUL_REF = 6 };
 enum { MSC_CH_AWGN = 0, MSC_CH_RAYLEIGH = 1 };
 
+/* ABI version of this header: bumped whenever an entry point's parameter list changes (a C caller built against another value
+ * must refuse to run: msc_abi_version() != MSC_ABI_VERSION).  3: msc_conv2d_dgrad gained relu_ref, msc_linear_dgrad gained res
+ * (round 3, both in the middle of their lists); msc_set_knob / msc_get_knob / msc_debug_last_gemm added (round 4). */
+#define MSC_ABI_VERSION 3
+
 const char* msc_strerror(int code);
 int msc_version(void);
+int msc_abi_version(void);
+/* Tuning / A-B knobs of the launch planner (csrc/gemm_plan.h `Knobs`: gemm_tile = bm*1000+bn, gemm_t128, conv_splitk, wgrad_blocks,
+ * wgrad_small, wgrad_small_max, wgrad_xcd_split, dgrad_cls_interleave, gemm_pp, gemm_pp_mask, att_bwd_waves, att_dq_waves).  Initial values come
+ * from the environment (MSC_<NAME>) ONCE, when the library is loaded; no launch reads the environment.  `name` is a host string.
+ * msc_set_knob: MSC_ERR_BAD_ARG for an unknown name; msc_get_knob: INT64_MIN for an unknown name. */
+int msc_set_knob(const char* name, int64_t value);
+int64_t msc_get_knob(const char* name);
+/* host_info8 (HOST pointer, 8 ints): the most recent contraction launch of this process — kind (1 one tile per workgroup, 2 persistent
+ * 256-row tiles, 3 persistent ping-pong), tile rows, tile columns, threads per workgroup, K slices, xcd_split, cls_interleave,
+ * extended-epilogue id.  Lets a test assert WHICH kernel variant a shape ran on. */
+int msc_debug_last_gemm(int* host_info8);
 /* sha256 (hex, first 16 digits) of the kernel sources + msc.h this library was built from (csrc/Makefile embeds it), so
    a test record can show that the loaded .so matches the checked-out sources */
 const char* msc_build_id(void);

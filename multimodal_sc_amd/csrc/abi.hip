@@ -12,7 +12,8 @@ extern "C" const char* msc_strerror(int code) {
     default: return "unknown error";
   }
 }
-extern "C" int msc_version(void) { return 200; }
+extern "C" int msc_version(void) { return 300; }
+extern "C" int msc_abi_version(void) { return MSC_ABI_VERSION; }
 #ifndef MSC_BUILD_ID
 #define MSC_BUILD_ID "unknown"
 #endif

@@ -14,6 +14,7 @@
 // Deterministic: every output element is produced by exactly one wave, no atomics.
 // Build-authored (the upstream reference has no code, SURVEY.md finding zero).  Role: FusionTransformer.
 #include "msc_common.h"
+#include "gemm_plan.h"     // mscplan::g_knobs (tuning knobs, msc_set_knob)
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
@@ -578,11 +579,11 @@ extern "C" int msc_attention_bwd(const void* qkv, const void* o, const void* dou
   const size_t lds = (size_t)2 * Tpad * 128;
   hipStream_t st = (hipStream_t)stream;
   const float c = scale * 1.4426950408889634f;
-  static int nwb_env = getenv("MSC_ATT_BWD_WAVES") ? atoi(getenv("MSC_ATT_BWD_WAVES")) : 0;   // tuning knob (A/B runs)
+  const int nwb_env = mscplan::g_knobs.att_bwd_waves;      // tuning knobs (msc_set_knob; 0 = default)
   // <= 8 waves: the kernels need ~190-256 VGPRs (two waves per SIMD); 8 measured best inside the step (5: -0.5 %)
   const int nt = Tpad / 32;
   const int nwb = nwb_env > 0 ? (nwb_env > 8 ? 8 : nwb_env) : (nt < 8 ? nt : 8);
-  static int nwq_env = getenv("MSC_ATT_DQ_WAVES") ? atoi(getenv("MSC_ATT_DQ_WAVES")) : 0;
+  const int nwq_env = mscplan::g_knobs.att_dq_waves;
   const int nwq = nwq_env > 0 ? (nwq_env > 8 ? 8 : nwq_env) : nwb;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(64 * nwq), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                      delta, (bf16_t*)dqkv, T, Tpad, H, c, scale);

@@ -32,33 +32,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-enum { OPM_DENSE_K = 0, OPM_DENSE_MN = 1, OPM_CONV_FWD = 2, OPM_CONV_DGRAD = 3, OPM_CONV_WGRAD = 4 };
-
-struct GemmParams {
-  const void* A; const void* B; void* C; void* C2; const void* res; const float* bias; float* stats;
-  int M, N, K;
-  long lda, ldb, ldc;
-  int batch_inner; long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
-  int nsplit, tiles_per_split;
-  float alpha; int act; int out_f32;
-  // geometry of the gathered NHWC tensor (conv modes)
-  int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
-  int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
-  int cls_interleave;       // set by the launcher when cMc is a multiple of the tile height it picked
-  unsigned long long* stamps;   // GEMM_STAMP diagnostic build only (else null and unused)
-  int bm_cap;                   // host only: largest tile height the launch may use (0 = no cap)
-  float* rowsum;                // weight-gradient launches (both operands mn-major): fp32 [nsplit][M] sums over the reduction of the
-                                // A operand's rows = the bias gradient (dy^T 1), produced by one extra MFMA against a ones fragment
-  int xcd_split;                // split-K launches: all tiles of one K slice on one XCD (see the kernel's index mapping)
-  const void* dref; int dact;   // epilogue: multiply by act'(dref[m][n]) (fused activation backward)
-  float* colsum;                // epilogue: per-row-block column sums of the stored output, [tile_m][N]
-  // epilogue (conv dgrad): the stored output is dy of the BatchNorm + ReLU that produced this layer's input.  bnx = that BatchNorm's
-  // input (the previous conv's output, [M][N]), bnstat = its [4][N] mean, rstd, scale, shift, bnpart = [tile_m][2][N] per-row-block
-  // sums of dz and dz*xhat with dz = dy * [x*scale+shift > 0] — the statistics pass of msc_bn_bwd, done where dy is produced
-  const void* bnx; const float* bnstat; float* bnpart;
-  int dephase_first;            // ... and the number of workgroups that make up round 1
-  int dephase;                  // GEMM_DEPHASE experiment build: s_sleep units (64 clk) the odd residency slot of each CU waits in round 1
-};
+#include "gemm_params.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -100,12 +74,6 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #endif
 #ifndef GEMM_P256_STAGES
 #define GEMM_P256_STAGES 4
-#endif
-#ifndef GEMM_PP_KB
-#define GEMM_PP_KB 128      // persistent 128x128 (8 waves, TWO workgroups per CU): 2 x 32 KB ring + 16 KB epilogue slab = 80 KB
-#endif
-#ifndef GEMM_PP_STAGES
-#define GEMM_PP_STAGES 2
 #endif
 #define MSCPLAN_NP_KB GEMM_NP_KB
 #include "gemm_plan.h"
@@ -597,19 +565,6 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
 
 #ifdef GEMM_STAMP
   unsigned long long st_entry = STAMP_NOW(), st_wait = 0, st_k = 0, st_ep = 0, st_first, st_tiles = 0, st_steps = 0;
-#endif
-#ifdef GEMM_DEPHASE
-  // Experiment: the two workgroups resident on a CU start round 1 together and then run K loop (LDS-bound) and epilogue (store
-  // burst) in phase.  HW_ID.TG_ID (bits 19:16) is the workgroup's slot on its CU: the odd slot of the FIRST round (the first
-  // 2 x #CUs workgroups in launch order) sleeps once; every later workgroup inherits its slot's phase.
-  if constexpr (!PERSIST) {
-    if (p.dephase > 0 && (int)(blockIdx.z * gridDim.x + blockIdx.x) < p.dephase_first) {
-      const unsigned hwid = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);     // HW_REG_HW_ID, offset 16, size 4 = TG_ID
-      if (hwid & 1u) {
-        for (int i = 0; i < p.dephase; ++i) __builtin_amdgcn_s_sleep(16);     // 1024 clocks per unit
-      }
-    }
-  }
 #endif
   issue_begin_tile(iw);
 #pragma unroll
@@ -1169,6 +1124,27 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   }
 }
 
+// gemm_pp.hip
+int msc_pp_tile_rows(const GemmParams& p, int ncu);
+int msc_pp_launch(const GemmParams& p, int ncu, hipStream_t st);
+// the most recent contraction launch of this process, for tests that assert which kernel variant a shape took (msc_debug_last_gemm):
+// kind (1 one tile per workgroup, 2 persistent 256-row, 3 ping-pong), bm, bn, threads, K slices, xcd_split, cls_interleave, extended epilogue
+static int g_last_gemm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static inline void note_gemm(int kind, int bm, int bn, int thr, int ns, int xs, int ci, int epx) {
+  g_last_gemm[0] = kind; g_last_gemm[1] = bm; g_last_gemm[2] = bn; g_last_gemm[3] = thr;
+  g_last_gemm[4] = ns; g_last_gemm[5] = xs; g_last_gemm[6] = ci; g_last_gemm[7] = epx;
+}
+extern "C" int msc_debug_last_gemm(int* host_info8) {
+  if (!host_info8) return MSC_ERR_BAD_ARG;
+  memcpy(host_info8, g_last_gemm, sizeof(g_last_gemm));
+  return MSC_OK;
+}
+extern "C" int msc_set_knob(const char* name, int64_t value) { return mscplan::knob_set(name, (long)value) ? MSC_OK : MSC_ERR_BAD_ARG; }
+extern "C" int64_t msc_get_knob(const char* name) {
+  long v = 0;
+  return mscplan::knob_get(name, v) ? (int64_t)v : (int64_t)INT64_MIN;
+}
+
 // ---- launch planning lives in gemm_plan.h (plain C++, fuzzed under ASan/UBSan by tests/host_san)
 static int num_cus() {
   static int n = 0;
@@ -1210,64 +1186,34 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   const mscplan::Tile t = tile_for(p.M, p.N, zs, AMODE, BMODE, DT, p.K, big, p.bm_cap ? p.bm_cap : 256);
   const int bm = t.bm, bn = t.bn;
   GemmParams q = p;
-  static const int cls_il = getenv("MSC_DGRAD_CLS_INTERLEAVE") ? atoi(getenv("MSC_DGRAD_CLS_INTERLEAVE")) : 1;   // A/B knob
-  q.cls_interleave = (AMODE == OPM_CONV_DGRAD && p.cls && cls_il && p.nsplit == 1 && p.cMc % bm == 0) ? 1 : 0;
-#ifdef GEMM_DEPHASE
-  {
-    const char* e = getenv("MSC_GEMM_DEPHASE");      // units of 1024 clocks (s_sleep 16); 0 = off
-    q.dephase = e ? atoi(e) : 0;
-    q.dephase_first = 2 * num_cus();
-  }
-#endif
+  q.cls_interleave = (AMODE == OPM_CONV_DGRAD && p.cls && mscplan::g_knobs.dgrad_cls_interleave && p.nsplit == 1 && p.cMc % bm == 0) ? 1 : 0;
   if (zs > 65535) return MSC_ERR_UNSUPPORTED;
-#ifdef GEMM_NP256_BUILD
-#ifndef GEMM_NP256_THREADS
-#define GEMM_NP256_THREADS 512      // 256: four waves with 128x64 wave tiles (the wave-tile shape of the vendor library's kernels on these shapes)
-#endif
-  // one-tile-per-workgroup 256x128 (8 waves, wave tile 64x64, 64-byte K steps x 3 stages = 72 KB: TWO workgroups per CU):
-  // 0.75x the staged bytes and DMA instructions per FLOP of the 128x128 tile.  Experiment build only (MSC_GEMM_NP256=1).
-  if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
-    const char* e = getenv("MSC_GEMM_NP256");
-    if (e && atoi(e) && p.M >= 256 && p.N >= 128 && zs == 1 && p.nsplit == 1 && !p.stats && !p.colsum && !(AMODE == OPM_CONV_DGRAD && p.cls)) {
-      dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, 128)), 1, 1);
-      hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, 64, 3, false, GEMM_NP256_THREADS>), grid, dim3(GEMM_NP256_THREADS), 0, st, q);
-      return msc_launch_status();
+  // dense bf16 linears (both operands k-major, one launch over the whole matrix): the persistent ping-pong kernel of gemm_pp.hip
+  if constexpr (DT == MSC_BF16 && AMODE == OPM_DENSE_K && BMODE == OPM_DENSE_K && EPX != 2) {
+    if (batch == 1 && msc_pp_tile_rows(p, num_cus())) {
+      note_gemm(3, msc_pp_tile_rows(p, num_cus()), 256, 512, 1, 0, 0, EPX);
+      return msc_pp_launch(p, num_cus(), st);
     }
   }
-#endif
   if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value && EPX != 2) {     // (EPX 2: never `big`)
     if (bm == 256) {     // persistent: one workgroup per CU walks the tiles
       const int ntiles = cdiv(p.M, 256) * cdiv(p.N, bn);
       const int ncu = num_cus();
       dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu), 1, 1);
+      note_gemm(2, 256, bn, 512, 1, 0, q.cls_interleave, EPX);
       if (bn == 256) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 256, EPX, GEMM_P256_KB, GEMM_P256_STAGES, true, 512>), grid, dim3(512), 0, st, q);
       else hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 256, 128, EPX, GEMM_P128_KB, GEMM_P128_STAGES, true, 512>), grid, dim3(512), 0, st, q);
       return msc_launch_status();
     }
   }
   if (bm > 128 || bn > 128) return MSC_ERR_UNSUPPORTED;
-#ifdef GEMM_P128_BUILD
-  // Persistent 128x128 with TWO workgroups per CU (8 waves, 2 x 32 KB ring + 16 KB slab = 80 KB, grid = 2 x #CUs, loader / storer
-  // wave roles): built and measured in round 3 (profiles/r3_gemm_p128_sweep.txt) — slower than one tile per workgroup on EVERY
-  // shape of the path (qkv 60 vs 51 us, fc1 128 vs 98, bev1 dgrad 355 vs 252; equal only where a launch has fewer tiles than
-  // slots).  Kept behind this build flag (make alt ALT_FLAGS=-DGEMM_P128_BUILD) for the record, not compiled into the product.
-  if constexpr (DT == MSC_BF16 && BMODE == OPM_DENSE_K && mode_is_kmajor<AMODE>::value) {
-    const char* e = getenv("MSC_GEMM_P128");      // A/B knob, read per call
-    const int ntiles = cdiv(p.M, 128) * cdiv(p.N, 128);
-    const int slots = 2 * num_cus();
-    if (bm == 128 && bn == 128 && zs == 1 && p.nsplit == 1 && !p.xcd_split && ntiles > slots && e && atoi(e)) {
-      dim3 grid((unsigned)slots, 1, 1);
-      hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX, GEMM_PP_KB, GEMM_PP_STAGES, true, 512>), grid, dim3(512), 0, st, q);
-      return msc_launch_status();
-    }
-  }
-#endif
   dim3 grid((unsigned)(cdiv(p.M, bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
   // K bytes per step / ring depth / waves of the multi-workgroup kernels (measured per operand mode, tools/gemm_sweep.py):
   // gathered weight gradients (conv wgrad) run best on 64-byte steps x 3 stages x 4 waves (three workgroups per CU);
   // everything else on 128-byte steps x 2 stages, the 128x128 tile with 8 waves
   constexpr bool WG = BMODE == OPM_CONV_WGRAD;
   constexpr int KBn = WG ? 64 : GEMM_NP_KB, S = WG ? GEMM_WG_STAGES : GEMM_NP_STAGES, W128 = WG ? 256 : 64 * GEMM_NP_W128;
+  note_gemm(1, bm, bn, (bm == 128 && bn == 128) ? W128 : 256, p.nsplit, p.xcd_split, q.cls_interleave, EPX);
   if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 128, EPX, KBn, S, false, W128>), grid, dim3(W128), 0, st, q);
   else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 128, 64, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, q);
   else if (bn == 128) hipLaunchKernelGGL((gemm_kernel<T, AMODE, BMODE, 64, 128, EPX, KBn, S, false, 256>), grid, dim3(256), 0, st, q);

@@ -41,12 +41,88 @@ static inline int kt_of_dtype(int dtype_is_f32) { return MSCPLAN_NP_KB / (dtype_
 
 struct Tile { int bm, bn; };
 
-// MSC_GEMM_TILE=BMxBN (tuning / A-B knob, read per call): force a tile where the operand modes allow it
+// Tuning / A-B knobs of the launch planner.  Read ONCE, when the library is loaded (the environment variable of the same name in
+// upper case with an MSC_ prefix gives the initial value); a process that wants to toggle one between launches (tests, sweeps) calls
+// msc_set_knob(name, value).  No launch path reads the environment.
+struct Knobs {
+  int tile_bm = 0, tile_bn = 0;      // gemm_tile: force a tile (value = bm * 1000 + bn; 0 = planner's choice)          MSC_GEMM_TILE=BMxBN
+  long t128 = 0;                     // gemm_t128: workgroup count below which a 128-wide tile shrinks to 64 (0 = default)
+  int conv_splitk = 1;               // conv_splitk: split-K for chip-underfilling conv forward / stride-1 dgrad launches
+  long wgrad_blocks = 640;           // wgrad_blocks: workgroup target of the weight-gradient K split
+  int wgrad_small = 1;               // wgrad_small: short K slices for outputs of 1-8 tiles
+  long wgrad_small_max = 512;        // wgrad_small_max
+  int wgrad_xcd_split = 1;           // wgrad_xcd_split: pin every K slice of a weight gradient to one XCD
+  int dgrad_cls_interleave = 1;      // dgrad_cls_interleave: parity classes of a strided dgrad interleaved in launch order
+  int gemm_pp = 1;                   // gemm_pp: dense bf16 linears on the persistent ping-pong kernel (gemm_pp.hip); 256/192/160: tile rows forced
+  int gemm_pp_k = 0;                 // gemm_pp_k: (bisecting aid) only contractions of this reduction length take the ping-pong kernel; 0 = any
+  int gemm_pp_mask = 15;             // gemm_pp_mask: which epilogue kinds may take it: 1 plain, 2 residual, 4 GELU + derivative, 8 dgrad x derivative
+  int att_bwd_waves = 0, att_dq_waves = 0;   // attention backward wave counts (0 = default)
+};
+static inline long knob_env(const char* name, long dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atol(e) : dflt;
+}
+static inline Knobs knobs_from_env() {
+  Knobs k;
+  if (const char* e = getenv("MSC_GEMM_TILE")) {
+    int bm = 0, bn = 0;
+    if (sscanf(e, "%dx%d", &bm, &bn) == 2) { k.tile_bm = bm; k.tile_bn = bn; }
+  }
+  k.t128 = knob_env("MSC_GEMM_T128", 0);
+  k.conv_splitk = (int)knob_env("MSC_CONV_SPLITK", 1);
+  k.wgrad_blocks = knob_env("MSC_WGRAD_BLOCKS", 640);
+  if (k.wgrad_blocks < 1) k.wgrad_blocks = 640;
+  k.wgrad_small = (int)knob_env("MSC_WGRAD_SMALL", 1);
+  k.wgrad_small_max = knob_env("MSC_WGRAD_SMALL_MAX", 512);
+  k.wgrad_xcd_split = (int)knob_env("MSC_WGRAD_XCD_SPLIT", 1);
+  k.dgrad_cls_interleave = (int)knob_env("MSC_DGRAD_CLS_INTERLEAVE", 1);
+  k.gemm_pp = (int)knob_env("MSC_GEMM_PP", 1);
+  k.gemm_pp_mask = (int)knob_env("MSC_GEMM_PP_MASK", 15);
+  k.gemm_pp_k = (int)knob_env("MSC_GEMM_PP_K", 0);
+  k.att_bwd_waves = (int)knob_env("MSC_ATT_BWD_WAVES", 0);
+  k.att_dq_waves = (int)knob_env("MSC_ATT_DQ_WAVES", 0);
+  return k;
+}
+inline Knobs g_knobs = knobs_from_env();
+// name -> field (msc_set_knob / msc_get_knob); nullptr: unknown name.  gemm_tile is handled by the callers (two fields).
+static inline long* knob_slot(const char* name, int*& as_int) {
+  as_int = nullptr;
+  Knobs& k = g_knobs;
+  if (!strcmp(name, "gemm_t128")) return &k.t128;
+  if (!strcmp(name, "wgrad_blocks")) return &k.wgrad_blocks;
+  if (!strcmp(name, "wgrad_small_max")) return &k.wgrad_small_max;
+  if (!strcmp(name, "conv_splitk")) as_int = &k.conv_splitk;
+  else if (!strcmp(name, "wgrad_small")) as_int = &k.wgrad_small;
+  else if (!strcmp(name, "wgrad_xcd_split")) as_int = &k.wgrad_xcd_split;
+  else if (!strcmp(name, "dgrad_cls_interleave")) as_int = &k.dgrad_cls_interleave;
+  else if (!strcmp(name, "gemm_pp")) as_int = &k.gemm_pp;
+  else if (!strcmp(name, "gemm_pp_mask")) as_int = &k.gemm_pp_mask;
+  else if (!strcmp(name, "gemm_pp_k")) as_int = &k.gemm_pp_k;
+  else if (!strcmp(name, "att_bwd_waves")) as_int = &k.att_bwd_waves;
+  else if (!strcmp(name, "att_dq_waves")) as_int = &k.att_dq_waves;
+  return nullptr;
+}
+static inline bool knob_set(const char* name, long v) {
+  if (!name) return false;
+  if (!strcmp(name, "gemm_tile")) { g_knobs.tile_bm = (int)(v / 1000); g_knobs.tile_bn = (int)(v % 1000); return true; }
+  int* ip = nullptr;
+  if (long* lp = knob_slot(name, ip)) { *lp = v; return true; }
+  if (ip) { *ip = (int)v; return true; }
+  return false;
+}
+static inline bool knob_get(const char* name, long& v) {
+  if (!name) return false;
+  if (!strcmp(name, "gemm_tile")) { v = (long)g_knobs.tile_bm * 1000 + g_knobs.tile_bn; return true; }
+  int* ip = nullptr;
+  if (long* lp = knob_slot(name, ip)) { v = *lp; return true; }
+  if (ip) { v = *ip; return true; }
+  return false;
+}
+
+// gemm_tile knob: force a tile where the operand modes allow it
 static inline bool forced_tile(Tile& t) {
-  const char* e = getenv("MSC_GEMM_TILE");
-  if (!e || !*e) return false;
-  int bm = 0, bn = 0;
-  if (sscanf(e, "%dx%d", &bm, &bn) != 2) return false;
+  const int bm = g_knobs.tile_bm, bn = g_knobs.tile_bn;
+  if (!bm && !bn) return false;
   if ((bm != 64 && bm != 128 && bm != 256) || (bn != 64 && bn != 128 && bn != 256)) return false;
   if (bn == 256 && bm != 256) return false;
   if (bm == 256 && bn == 64) return false;
@@ -72,8 +148,7 @@ static inline Tile choose_tile(long M, long N, long zs, bool allow256, long ncu 
   if (forced_tile(f)) {
     if ((f.bm < 256 || allow256) && f.bm <= bm_cap) return f;
   }
-  static const long T128env = getenv("MSC_GEMM_T128") ? atol(getenv("MSC_GEMM_T128")) : 0;   // A/B knob
-  const long T128 = T128env ? T128env : (min_wgs ? min_wgs : 200);                            // below: shrink to 64-wide
+  const long T128 = g_knobs.t128 ? g_knobs.t128 : (min_wgs ? min_wgs : 200);                  // below: shrink to 64-wide
   // The persistent 256x256 kernel pays only on LARGE contractions (measured, tools/gemm_sweep.py / gemm_big.py): at this
   // path's short K and 1-4 tiles per CU the per-CU store throughput (~8 B/clk) makes every epilogue as long as the K loop
   // and all workgroups hit it together; several smaller workgroups per CU overlap those phases better.
@@ -85,11 +160,9 @@ static inline Tile choose_tile(long M, long N, long zs, bool allow256, long ncu 
 
 // Split-K for chip-underfilling conv forward / stride-1 dgrad launches (deep ResNet layers: 64 frames x 7x7 or 14x14
 // pixels give 100-200 tiles of 128x128 for 256 CUs): 128x128 tiles over ns K slices + a fixed-order finish kernel.
-// nk = K steps.  Returns 1 when the launch fills the chip or K is too short to split.  MSC_CONV_SPLITK=0 switches it off
-// (read per call so a test can toggle it inside one process).
+// nk = K steps.  Returns 1 when the launch fills the chip or K is too short to split.  Knob conv_splitk = 0 switches it off.
 static inline int plan_conv_split(long M, long N, long nk) {
-  const char* e = getenv("MSC_CONV_SPLITK");
-  const int on = e ? atoi(e) : 1;
+  const int on = g_knobs.conv_splitk;
   const long tiles = cdivl(M, 128) * cdivl(N, 128);
   if (!on || tiles >= 200 || nk < 16 || N % 4) return 1;
   long ns = (400 + tiles / 2) / tiles;     // ~400 workgroups (measured: layer3 best at 2 slices, layer4 at 4)
@@ -117,18 +190,13 @@ static inline int plan_split(long rows_out, long cols_out, long reduce_len) {
   // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~640 workgroups measured best
   // (fewer: underfilled when the main stream idles; more: fp32 slab traffic = nsplit x output).  Same-box sweep of the step
   // at the end of round 2 (XCD pinning really applied, fusion as two chains): 384: +0.09 ms, 512: +0.05, 640: 0, 768: +0.07.
-  static long target = 0;
-  if (!target) {
-    const char* e = getenv("MSC_WGRAD_BLOCKS");   // tuning knob (A/B runs)
-    target = e ? atol(e) : 640;
-    if (target < 1) target = 640;
-  }
+  const long target = g_knobs.wgrad_blocks > 0 ? g_knobs.wgrad_blocks : 640;
   long want = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
   // A slice is a SERIAL K loop of one workgroup.  Outputs of one to four tiles (1x1 downsample convolutions: 16 workgroups x 25 steps ran
   // 50 us for 0.8 GFLOP; the stem: 256 workgroups x 98 steps, 150 us, the last kernel of the backward) are latency-bound on that
-  // loop and their slabs are small: shorter slices (>= 256 reduction rows) and up to 512 of them.  MSC_WGRAD_SMALL=0: the old limits.
-  static const int small_on = getenv("MSC_WGRAD_SMALL") ? atoi(getenv("MSC_WGRAD_SMALL")) : 1;     // A/B knob
-  static const long small_max = getenv("MSC_WGRAD_SMALL_MAX") ? atol(getenv("MSC_WGRAD_SMALL_MAX")) : 512;   // A/B knob
+  // loop and their slabs are small: shorter slices (>= 256 reduction rows) and up to 512 of them.  Knob wgrad_small = 0: the old limits.
+  const int small_on = g_knobs.wgrad_small;
+  const long small_max = g_knobs.wgrad_small_max;
   const bool small = small_on && tiles <= 4;
   long cap = reduce_len / (small_on && tiles <= 8 ? 256 : 1024);
   if (want > cap) want = cap;
@@ -136,7 +204,7 @@ static inline int plan_split(long rows_out, long cols_out, long reduce_len) {
   const long maxw = small ? small_max / tiles : 128;
   if (want > maxw) want = maxw;
   // multiples of 8 let the kernel pin each K slice to one XCD (xcd_split)
-  static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;   // A/B knob
+  const int xs = g_knobs.wgrad_xcd_split;
   if (xs && want >= 6) {
     long w8 = (want + 4) / 8 * 8;
     if (w8 > cap) w8 = cap / 8 * 8;
@@ -158,7 +226,7 @@ static inline WgradSplit wgrad_split(long rows_out, long cols_out, long reduce_l
   WgradSplit w;
   w.tps = (int)cdivl(nk, planned);
   w.ns = (int)cdivl(nk, w.tps);
-  static const int xs = getenv("MSC_WGRAD_XCD_SPLIT") ? atoi(getenv("MSC_WGRAD_XCD_SPLIT")) : 1;
+  const int xs = g_knobs.wgrad_xcd_split;
   // the slice count that really runs is cdiv(nk, tps), often planned - 1: lengthen the slices a little (at most 25 %) until
   // it is a multiple of 8 again, or the XCD pinning below silently never applies (layer 1 at 64 frames: 104 planned, 103 ran)
   if (xs && planned >= 8 && w.ns % 8 != 0) {

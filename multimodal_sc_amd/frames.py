@@ -128,6 +128,7 @@ class FrameStager:
 
     def _fill_loop(self):
         torch.cuda.set_device(self.rt.device)        # (HIP's current device is per host thread)
+        L.no_record()                                # this thread's calls run beside the step, never inside a recorded launch list
         k = 0
         while not self._stop:
             try:

@@ -542,7 +542,11 @@ def attention_bwd(rt: Runtime, do, qkv, o, P, B, T, h, hd):
     return dqkv
 
 
-_FUSION_CHAINS = os.environ.get("MSC_FUSION_CHAINS", "2") != "1"     # A/B knob: 1 = the whole batch as one chain of launches
+# MSC_FUSION_CHAINS: 1 = the whole batch as one chain of launches, 2 / force = two half-batch chains.  Default (round 4): ONE chain while
+# the dense linears run on the persistent ping-pong kernel (knob gemm_pp): that kernel owns a CU (136-160 KB of LDS) and overlaps its own
+# load / MFMA / store phases, so two concurrent half-size launches only take turns (same box: 7.71 vs 7.52 ms); two chains with the
+# tiled kernel (gemm_pp = 0), whose lock-step phases the second chain interleaves (round 2: 8.10 -> 7.95 ms).
+_FUSION_CHAINS = (os.environ["MSC_FUSION_CHAINS"] != "1") if "MSC_FUSION_CHAINS" in os.environ else (L.lib.msc_get_knob(b"gemm_pp") == 0)
 _CHAIN_MIN_ROWS = 0 if os.environ.get("MSC_FUSION_CHAINS") == "force" else 11264   # token rows (B*T) from which two chains pay
 
 

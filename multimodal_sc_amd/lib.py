@@ -7,6 +7,7 @@ from __future__ import annotations
 import ctypes
 import os
 import re
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "msc.h")
@@ -94,6 +95,13 @@ def stream_ptr():
 _FN = {}
 _SCALARS = (int, float, bool)
 _REC = None     # active replay.Recorder (None: not recording)
+_TLS = threading.local()
+
+
+def no_record():
+    """Mark the CALLING thread as one whose lib.call()s never belong to a recorded training step (helper threads that run beside
+    the step: the frame stager's filler).  _REC is process-global, and autograd's engine threads must stay recorded."""
+    _TLS.norecord = True
 
 
 def _dev(a):
@@ -110,7 +118,7 @@ def call(name: str, *args):
     rc = fn(*conv)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {lib.load().msc_strerror(rc).decode()} (code {rc})")
-    if _REC is not None:
+    if _REC is not None and not getattr(_TLS, "norecord", False):
         _REC.add(name, conv, args)
     return rc
 

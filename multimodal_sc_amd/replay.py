@@ -26,6 +26,11 @@ class Recorder:
         self.labels = []
 
     def add(self, name, conv, raw):
+        # A host-blocking wait never belongs in a replayed list (every replay would stall the host on a pending H2D copy); calls of
+        # threads that opted out (lib.no_record(): the frame stager's filler thread) are dropped in lib.call.  NOT a "recording
+        # thread only" filter: autograd runs the backward of a step on its own engine thread, and those launches ARE the step.
+        if name == "msc_event_synchronize":
+            return
         self.recs.append((name, conv))
         for a in raw:
             if hasattr(a, "data_ptr"):

@@ -227,7 +227,12 @@ class Runtime:
         return torch.cuda.ExternalStream(h, device=self.device)
 
     def join_side(self):
-        if self.side is not None and self._side_dirty:
+        # While a step is being RECORDED (replay.Recorder active) the wait is emitted unconditionally: the recorded program is
+        # replayed after steps whose side stream is always busy (upper-half Adam, weight transposes, draw-counter bump), whatever
+        # the host flag said about the step that happened to be recorded (a clean side stream after export_state_dict /
+        # load_oracle_state_dict / a no-grad forward would otherwise bake "no wait" into every later replay: a silent race on
+        # P / C / TR between the side stream's optimizer tail and the fusion, codec and heads of the next step).
+        if self.side is not None and (self._side_dirty or L._REC is not None):
             self.stream_wait(self.stream, self._side_raw)
             self._side_dirty = False
             self._side_keep.clear()

@@ -121,6 +121,9 @@ class Trainer:
         self.n_buckets = n_buckets
         self.use_ppo = use_ppo
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # data-parallel code path (two-phase backward, GradExchange, replay segments cut at the collectives).  MSC_DP_FORCE=1 takes it
+        # with a ONE-rank process group too: the only way RCCL itself can execute this schedule on a one-GPU box (tests/test_dp_gpu.py)
+        self.dp = self.world > 1 or (os.environ.get("MSC_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
         if self.world > 1:
             model.channel_rank = dist.get_rank()      # every rank draws its own channel noise (Philox key word)
         self.overlap = os.environ.get("MSC_DP_OVERLAP", "1") != "0"
@@ -129,7 +132,7 @@ class Trainer:
         if self.use_graph:
             model.rt.host_counters = False     # a replayed launch sequence needs its step / noise-draw numbers on the device
         self.dp_pieces = int(os.environ.get("MSC_DP_PIECES", "3"))    # 2: upper + encoders; 3: upper + mid + rest of the trunk
-        if self.world > 1 and getattr(model, "_img_cut_auto", False) and self.overlap and self.dp_pieces >= 3 and not self.use_graph:
+        if self.dp and getattr(model, "_img_cut_auto", False) and self.overlap and self.dp_pieces >= 3 and not self.use_graph:
             # boundary inside the camera trunk: the exchange's mid piece starts there.  Only the schedule that issues a mid piece
             # pays for the boundary (one GPU: 8.12 -> 8.25 ms); two-piece, non-overlapped and hipGraph DP keep the uncut trunk
             model._img_cut = 3
@@ -157,7 +160,7 @@ class Trainer:
     def _forward_upper(self, batch):
         m = self.model
         out = m(batch["image"], batch.get("points"), batch.get("state"), batch["snr_db"], batch.get("noise"), batch.get("fading"))
-        two_phase = self.world > 1 and self.overlap
+        two_phase = self.dp and self.overlap
         terms = m.loss_and_grads(out, batch["image"], batch.get("ppo") if self.use_ppo else None, lower=not two_phase)
         if two_phase:
             m.rt.join_side()          # upper weight gradients (side stream) are final behind this point
@@ -201,7 +204,7 @@ class Trainer:
 
     def _eager_step(self, batch):
         m, G = self.model, self.model.params.G
-        if self.world == 1:
+        if not self.dp:
             _, terms = self.forward_backward(batch)
         elif self.overlap:
             _, terms = self._forward_upper(batch)
@@ -326,7 +329,7 @@ class Trainer:
         torch.cuda.synchronize(m.rt.device)
         gA, gB, gC = torch.cuda.CUDAGraph(), None, None
         pool = None
-        if self.world == 1:
+        if not self.dp:
             with torch.cuda.graph(gA):
                 _, terms = self.forward_backward(batch)
                 self._adam()
@@ -360,7 +363,7 @@ class Trainer:
         gA, gB, gC = self._graphs
         G = self.model.params.G
         gA.replay()
-        if self.world > 1:
+        if self.dp:
             if gB is not None:
                 ex = GradExchange(G.numel(), self.split, None, 2)
                 works = [ex.start(G, "upper")]

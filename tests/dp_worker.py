@@ -1,6 +1,8 @@
 """Child process of tests/test_dp_gpu.py: one data-parallel rank running Trainer.step on cuda:0.
 usage: python dp_worker.py <rank> <world> <port> <out.pt> <config> <frames> <steps> [shard]
-world == 1: a single-process run (no process group) of shard `shard` — the independent answer the DP runs are checked against.
+world == 1: a single-process run (no process group) of shard `shard` — the independent answer the DP runs are checked against;
+with MSC_DP_FORCE=1 in the environment it initialises a ONE-rank process group on MSC_DP_BACKEND (nccl = RCCL) and the Trainer takes the
+data-parallel code path (exit code 77 + "RCCL_UNAVAILABLE: ..." on stdout when the communicator cannot be created on this box).
 Ranks share the one GPU of the test box and exchange gradients through gloo (host memory) — the same Trainer code path
 the real runs take over RCCL, one rank per GPU.  Schedule knobs (MSC_DP_PIECES, MSC_DP_OVERLAP) come from the environment."""
 import os
@@ -21,8 +23,23 @@ def main():
     from multimodal_sc_amd.synthetic import synthetic_batch
     from multimodal_sc_amd.trainer import Trainer
     torch.cuda.set_device(0)
+    forced = world == 1 and os.environ.get("MSC_DP_FORCE") == "1"
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif forced:
+        backend = os.environ.get("MSC_DP_BACKEND", "nccl")
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+            else:
+                dist.init_process_group(backend, rank=0, world_size=1)
+            probe = torch.ones(1024, device="cuda:0")
+            dist.all_reduce(probe)                      # the communicator is created lazily: make it exist (or fail) here
+            torch.cuda.synchronize()
+            assert float(probe.sum()) == 1024.0
+        except Exception as e:  # noqa: BLE001 — reported to the test, which records the text and xfails
+            print("RCCL_UNAVAILABLE:", type(e).__name__, str(e).replace("\n", " | ")[:1500], flush=True)
+            sys.exit(77)
     cfg = named_config(cfg_name)
     m = MultimodalSC(cfg, dtype="bf16", device="cuda:0", seed=0)          # same seed: identical initial parameters
     tr = Trainer(m, lr=1e-3)
@@ -38,7 +55,7 @@ def main():
     log = list(tr.exchange.log) if tr.exchange is not None else []
     replayed = any(st["prog"] is not None for st in tr._programs.values())
     torch.save({"P": m.params.P.cpu(), "G": m.params.G.cpu(), "log": log, "replayed": replayed}, out)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

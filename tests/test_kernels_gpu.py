@@ -221,11 +221,11 @@ PERSIST_TILES = ["256x128", "256x256"]
                                            (2100, 512, 64, 2, False),     # K = one step: the issue side rolls over tiles faster than the ring depth
                                            (1024, 256, 2048, 3, True),    # long K, few tiles (fewer tiles than CUs)
                                            (33000, 200, 328, 1, False)])  # N not a tile multiple, K not a step multiple
-def test_persistent_linear_fwd(rts, monkeypatch, tile, M, N, K, act, res):
+def test_persistent_linear_fwd(rts, knob, tile, M, N, K, act, res):
     """the persistent kernels (one workgroup per CU walking the tiles, next tile's DMA in flight under the epilogue) forced
     on shapes that stress the tile roll-over, against fp32 from the bf16-rounded inputs"""
     rt = rts["bf16"]
-    monkeypatch.setenv("MSC_GEMM_TILE", tile)
+    knob("gemm_tile", tile)
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
     r = rnd(M, N, seed=4) if res else None
     pre = q(x, "bf16") @ q(w, "bf16").t() + b
@@ -245,13 +245,13 @@ def test_persistent_linear_fwd(rts, monkeypatch, tile, M, N, K, act, res):
 
 
 @pytest.mark.parametrize("tile", PERSIST_TILES)
-def test_persistent_linear_dgrad_fused(rts, monkeypatch, tile):
+def test_persistent_linear_dgrad_fused(rts, knob, tile):
     """extended epilogue in the persistent kernels: act' of the saved pre-activation.  (Launches that also emit per-row-block
     column sums or BatchNorm partials never take the persistent kernels — their side buffers are sized by queries that know
     only (rows, cols) — so the same call WITH the column sums must fall back to the 128-row tiles and still be right.)"""
     from multimodal_sc_amd import lib as L
     rt = rts["bf16"]
-    monkeypatch.setenv("MSC_GEMM_TILE", tile)
+    knob("gemm_tile", tile)
     M, N, K = 40000, 192, 512
     dy, w, pre = rnd(M, N, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(N)), rnd(M, K, seed=3)
     pq = q(pre, "bf16").requires_grad_()
@@ -273,12 +273,12 @@ def test_persistent_linear_dgrad_fused(rts, monkeypatch, tile):
 
 @pytest.mark.parametrize("tile", PERSIST_TILES)
 @pytest.mark.parametrize("case", [(6, 48, 48, 64, 128, 3, 1, 1), (5, 40, 40, 64, 256, 3, 2, 1), (3, 64, 64, 128, 256, 1, 2, 0)])
-def test_persistent_conv_fwd_dgrad(rts, monkeypatch, tile, case):
+def test_persistent_conv_fwd_dgrad(rts, knob, tile, case):
     """implicit-GEMM convolution through the persistent kernels: forward with the fused BatchNorm partial sums, data
     gradient with the residual add — stride 1, stride 2 (parity-class-major rows, per-tile tap schedules) and 1x1/2."""
     from multimodal_sc_amd import lib as L
     rt = rts["bf16"]
-    monkeypatch.setenv("MSC_GEMM_TILE", tile)
+    knob("gemm_tile", tile)
     B, H, W, Cin, Cout, K, s, p = case
     Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
     x = rnd(B, H, W, Cin, seed=1)

@@ -63,3 +63,24 @@ def test_recorder_hooks_lib_call_and_restores(L):
         with pytest.raises(RuntimeError, match="already active"):
             Recorder().__enter__()
     assert L._REC is None and rec.recs == []
+
+
+def test_recorder_ignores_opted_out_threads_and_blocking_waits(L):
+    """lib._REC is process-global: the frame stager's filler thread calls lib.call beside a step.  A thread that called
+    lib.no_record() is never recorded, a host-blocking msc_event_synchronize never is — and any OTHER thread is (autograd runs the
+    backward of a step on its engine thread: those launches are the step)."""
+    import threading
+    from multimodal_sc_amd.replay import Recorder
+
+    def helper():
+        L.no_record()
+        L.call("msc_set_knob", b"gemm_t128", 0)
+
+    with Recorder() as rec:
+        L.call("msc_set_knob", b"gemm_pp", 1)                       # (a harmless int-returning entry point that needs no device)
+        for fn in (helper, lambda: L.call("msc_set_knob", b"conv_splitk", 1)):
+            th = threading.Thread(target=fn)
+            th.start()
+            th.join()
+        rec.add("msc_event_synchronize", [0], [])
+    assert [c[0] for _, c in rec.recs] == [b"gemm_pp", b"conv_splitk"]
