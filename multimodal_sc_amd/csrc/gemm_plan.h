@@ -57,6 +57,7 @@ struct Knobs {
   int gemm_pp_k = 0;                 // gemm_pp_k: (bisecting aid) only contractions of this reduction length take the ping-pong kernel; 0 = any
   int gemm_pp_mask = 15;             // gemm_pp_mask: which epilogue kinds may take it: 1 plain, 2 residual, 4 GELU + derivative, 8 dgrad x derivative
   int att_bwd_waves = 0, att_dq_waves = 0;   // attention backward wave counts (0 = default)
+  int bn_un = 1;                     // bn_un: rows per thread in flight in the BatchNorm-backward reduction (1 or 4)
 };
 static inline long knob_env(const char* name, long dflt) {
   const char* e = getenv(name);
@@ -81,6 +82,7 @@ static inline Knobs knobs_from_env() {
   k.gemm_pp_k = (int)knob_env("MSC_GEMM_PP_K", 0);
   k.att_bwd_waves = (int)knob_env("MSC_ATT_BWD_WAVES", 0);
   k.att_dq_waves = (int)knob_env("MSC_ATT_DQ_WAVES", 0);
+  k.bn_un = (int)knob_env("MSC_BN_UN", 1);
   return k;
 }
 inline Knobs g_knobs = knobs_from_env();
@@ -100,6 +102,7 @@ static inline long* knob_slot(const char* name, int*& as_int) {
   else if (!strcmp(name, "gemm_pp_k")) as_int = &k.gemm_pp_k;
   else if (!strcmp(name, "att_bwd_waves")) as_int = &k.att_bwd_waves;
   else if (!strcmp(name, "att_dq_waves")) as_int = &k.att_dq_waves;
+  else if (!strcmp(name, "bn_un")) as_int = &k.bn_un;
   return nullptr;
 }
 static inline bool knob_set(const char* name, long v) {

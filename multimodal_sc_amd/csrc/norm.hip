@@ -5,11 +5,9 @@
 // Roles: ImageEncoder / BEV conv stack (BN), FusionTransformer (LN).  Build-authored; the upstream reference has no
 // code (SURVEY.md finding zero).
 #include "msc_common.h"
+#include "gemm_plan.h"     // mscplan::g_knobs (tuning knobs, msc_set_knob)
 
 #define BN_MAX_BLOCKS 1024
-#ifndef BN_UN
-#define BN_UN 1      // rows per thread in flight in the BatchNorm-backward reduction (4: faster alone, no gain inside the step)
-#endif
 #ifndef LN_UR
 #define LN_UR 1      // rows per wave in flight in the LayerNorm backward (2: no gain inside the step)
 #endif
@@ -98,9 +96,47 @@ template <int VEC> __device__ __forceinline__ void ldc(const float* __restrict__
   }
 }
 
-// y = relu?( x*scale[c] + shift[c] + res? )
+// y = relu?( x*scale[c] + shift[c] + res? ).  The grid stride (gridDim * 256 vectors) is a multiple of C / VEC (a power of two <= 64),
+// so a thread meets the same 16-byte channel group in every iteration: the per-channel constants are loaded once, and UN vectors per
+// operand are in flight per thread (the kernel is a pure stream: the more bytes in flight per CU, the closer to the HBM rate).
+template <typename T, int UN>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const T* __restrict__ res, T* __restrict__ y, long nvec, int C, int relu) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const unsigned ncv = (unsigned)C / VEC;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  const int c0 = (int)((unsigned)(i0 % ncv) * VEC);
+  float sc[VEC], sh[VEC];
+  ldc<VEC>(scale + c0, sc);
+  ldc<VEC>(shift + c0, sh);
+  for (long i = i0; i < nvec; i += stride * UN) {
+    vecf<T> vx[UN], vr[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = (i + u * stride) * VEC;
+      if (i + u * stride < nvec) {
+        vx[u].load(x + e);
+        if (res) vr[u].load(res + e);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (i + u * stride >= nvec) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = fmaf(vx[u].v[j], sc[j], sh[j]);
+        if (res) v += vr[u].v[j];
+        if (relu) v = v > 0.f ? v : 0.f;
+        vx[u].v[j] = v;
+      }
+      vx[u].store(y + (i + u * stride) * VEC);
+    }
+  }
+}
+
+// the same for channel counts whose 16-byte groups do not divide 256 (a thread then meets another group every iteration)
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+__global__ void bn_apply_any_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                 const T* __restrict__ res, T* __restrict__ y, long nvec, int C, int relu) {
   constexpr int VEC = msc_traits<T>::VEC;
   // channel of the vector, kept incrementally: a 64-bit modulo per 16-byte vector costs more than the rest of the body
@@ -133,14 +169,13 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
 // latency-bound otherwise: one 16-B load per operand per iteration left the kernel at ~2 TB/s).
 // scale != nullptr: the ReLU mask is rebuilt as x*scale+shift > 0 (the forward's folded affine; valid when the forward had no
 // residual input) and y is not read.
-template <typename T>
+template <typename T, int UN>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ partial,
                                                             long rows, int C, int relu, int rows_per_block) {
   constexpr int VEC = msc_traits<T>::VEC;
-  constexpr int UN = BN_UN;
   const int ncx = C / VEC;          // threads across channels
   const int nty = 256 / ncx;        // rows handled concurrently
   const int tx = threadIdx.x % ncx, ty = threadIdx.x / ncx;
@@ -208,9 +243,65 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// Stage 3: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M); dres = dz (optional).  scale != nullptr: mask from x (see stage 1)
+// Stage 3: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M); dres = dz (optional).  scale != nullptr: mask from x (see stage 1).
+// As bn_apply_kernel: the thread's channel group is fixed, its constants (folded into three per channel: dx = a*dz + b*x + c) are
+// computed once, UN vectors per operand are in flight.
+template <typename T, int UN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ sum_dz,
+                                                           const float* __restrict__ sum_dzx, T* __restrict__ dx, T* __restrict__ dres,
+                                                           long nvec, int C, int relu, float inv_rows) {
+  constexpr int VEC = msc_traits<T>::VEC;
+  const bool xmask = relu && scale != nullptr;
+  const bool ymask = relu && scale == nullptr;
+  const unsigned ncv = (unsigned)C / VEC;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  const int c0 = (int)((unsigned)(i0 % ncv) * VEC);
+  float mu[VEC], rs[VEC], ga[VEC], sa[VEC], sb[VEC], sc[VEC], sh[VEC];
+  ldc<VEC>(mean + c0, mu);
+  ldc<VEC>(rstd + c0, rs);
+  ldc<VEC>(gamma + c0, ga);
+  ldc<VEC>(sum_dz + c0, sa);
+  ldc<VEC>(sum_dzx + c0, sb);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = 0.f; sh[j] = 0.f; }
+  if (xmask) { ldc<VEC>(scale + c0, sc); ldc<VEC>(shift + c0, sh); }
+  for (long i = i0; i < nvec; i += stride * UN) {
+    vecf<T> vd[UN], vx[UN], vy[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = (i + u * stride) * VEC;
+      if (i + u * stride < nvec) {
+        vd[u].load(dy + e);
+        vx[u].load(x + e);
+        if (ymask) vy[u].load(y + e);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (i + u * stride >= nvec) break;
+      const long e = (i + u * stride) * VEC;
+      vecf<T> vo;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float dz = vd[u].v[j];
+        if (ymask && !(vy[u].v[j] > 0.f)) dz = 0.f;
+        if (xmask && !(fmaf(vx[u].v[j], sc[j], sh[j]) > 0.f)) dz = 0.f;
+        const float xh = (vx[u].v[j] - mu[j]) * rs[j];
+        vo.v[j] = ga[j] * rs[j] * (dz - sa[j] * inv_rows - xh * sb[j] * inv_rows);
+        vd[u].v[j] = dz;
+      }
+      vo.store(dx + e);
+      if (dres) vd[u].store(dres + e);
+    }
+  }
+}
+
+// stage 3 for channel counts whose 16-byte groups do not divide 256
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+__global__ void bn_bwd_apply_any_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ sum_dz,
@@ -628,6 +719,16 @@ static inline int ew_blocks(long n) {
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
+// grid of the BatchNorm streaming kernels: UN vectors per thread and iteration, at most 8 blocks of 256 threads per CU (2048 blocks) —
+// enough waves to cover the HBM latency with UN x 16 B per operand in flight per lane, few enough that every thread iterates
+#ifndef BN_APPLY_UN
+#define BN_APPLY_UN 4
+#endif
+static inline int bn_stream_blocks(long nvec, int un) {
+  long b = (nvec + 256L * un - 1) / (256L * un);
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
 // ================================================================ C-ABI
 extern "C" int msc_bn_finalize(const float* partial, int nblk, int C, int64_t count, float eps, const float* gamma,
                                const float* beta, float* mean, float* rstd, float* scale, float* shift, void* stream) {
@@ -657,13 +758,19 @@ extern "C" int msc_bn_apply(const void* x, const float* scale, const float* shif
   if (dtype == MSC_F32) {
     MSC_CHECK_ARG(C % 4 == 0);
     const long nvec = rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const float*)x, scale, shift,
-                       (const float*)res, (float*)y, nvec, C, relu);
+    if (256 % (C / 4) == 0)
+      hipLaunchKernelGGL((bn_apply_kernel<float, BN_APPLY_UN>), dim3(bn_stream_blocks(nvec, BN_APPLY_UN)), dim3(256), 0, st, (const float*)x, scale, shift,
+                         (const float*)res, (float*)y, nvec, C, relu);
+    else
+      hipLaunchKernelGGL(bn_apply_any_kernel<float>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const float*)x, scale, shift, (const float*)res, (float*)y, nvec, C, relu);
   } else if (dtype == MSC_BF16) {
     MSC_CHECK_ARG(C % 8 == 0);
     const long nvec = rows * C / 8;
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const bf16_t*)x, scale, shift,
-                       (const bf16_t*)res, (bf16_t*)y, nvec, C, relu);
+    if (256 % (C / 8) == 0)
+      hipLaunchKernelGGL((bn_apply_kernel<bf16_t, BN_APPLY_UN>), dim3(bn_stream_blocks(nvec, BN_APPLY_UN)), dim3(256), 0, st, (const bf16_t*)x, scale, shift,
+                         (const bf16_t*)res, (bf16_t*)y, nvec, C, relu);
+    else
+      hipLaunchKernelGGL(bn_apply_any_kernel<bf16_t>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (const bf16_t*)res, (bf16_t*)y, nvec, C, relu);
   } else
     return MSC_ERR_BAD_ARG;
   return msc_launch_status();
@@ -700,14 +807,21 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* m
     const int rpb = cdiv(rows, nblk);
     nblk = cdiv(rows, rpb);
     float* partial = ws;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y,
-                       mean, rstd, scale, shift, partial, (long)rows, C, relu, rpb);
+    if (mscplan::g_knobs.bn_un >= 4)
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y,
+                         mean, rstd, scale, shift, partial, (long)rows, C, relu, rpb);
+    else
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(nblk), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y,
+                         mean, rstd, scale, shift, partial, (long)rows, C, relu, rpb);
     launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
   }
   const long nvec = rows * C / VEC;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dy, (const T*)x,
-                     (const T*)y, mean, rstd, gamma, scale, shift, sums, sums + C, (T*)dx, (T*)dres, nvec, C, relu,
-                     1.f / (float)rows);
+  if (256 % ncx == 0)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, BN_APPLY_UN>), dim3(bn_stream_blocks(nvec, BN_APPLY_UN)), dim3(256), 0, st, (const T*)dy, (const T*)x,
+                       (const T*)y, mean, rstd, gamma, scale, shift, sums, sums + C, (T*)dx, (T*)dres, nvec, C, relu, 1.f / (float)rows);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_any_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)dy, (const T*)x,
+                       (const T*)y, mean, rstd, gamma, scale, shift, sums, sums + C, (T*)dx, (T*)dres, nvec, C, relu, 1.f / (float)rows);
   return msc_launch_status();
 }
 
@@ -776,7 +890,7 @@ static int bn_pool_bwd_t(const void* dpool, const uint8_t* idx, const void* xsel
   nblk = cdiv(prow, rpb);
   float* partial = ws;
   float* sums = ws + (long)BN_MAX_BLOCKS * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, (const T*)dpool, (const T*)xsel, (const T*)nullptr, mean, rstd, scale,
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, (const T*)dpool, (const T*)xsel, (const T*)nullptr, mean, rstd, scale,
                      shift, partial, prow, C, 1, rpb);
   launch_fin_sums(partial, nblk, C, sums, sums + C, dbeta, dgamma, accumulate, st);
   const long nvec = rows * C / VEC;
