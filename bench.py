@@ -31,13 +31,13 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
-PMC_HBM_SUMMARY = "profiles/r3_pmc_hbm_bench_c3.csv"
+PMC_HBM_SUMMARY = "profiles/r4_pmc_hbm_bench_c3.csv"
 
 
 def gemm_source_sha():
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm_plan.h"):        # the kernel and its launch planning (tile choice, split counts)
+    for f in ("gemm.hip", "gemm_pp.hip", "gemm_plan.h"):        # the kernels and their launch planning (tile choice, split counts)
         h.update(open(os.path.join(ROOT, "multimodal_sc_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -58,7 +58,7 @@ def pmc_hbm_bytes_per_gemm_launch(n_launches_instrumented=0):
         return None, f"{PMC_HBM_SUMMARY} is stale (csrc/gemm.hip or gemm_plan.h changed since the PMC pass)"
     b = n = 0.0
     for r in csv.DictReader(open(path)):
-        if "gemm_kernel<unsigned short" in r["kernel"]:
+        if "gemm_kernel<unsigned short" in r["kernel"] or "gemm_pp_kernel<" in r["kernel"]:
             b += float(r["fetch_bytes_corrected_x2"]) + float(r["write_bytes"])
             n += int(r["calls"])
     # The profiled run is the normal multi-stream step, where the fusion layers launch every dense GEMM twice (two half-batch
@@ -519,7 +519,7 @@ def main(argv=None):
 
     if rank == 0 and not args.no_roofline:
         # instrumented pass: every kernel alone on one stream, HIP events on that stream around every C-ABI call (see instrumented_pass);
-        # profiles/r3_kernel_stats_instrumented.csv is `rocprofv3 --kernel-trace --stats` of `bench.py --instrumented-only 8`
+        # profiles/r4_kernel_stats_instrumented.csv is `rocprofv3 --kernel-trace --stats` of `bench.py --instrumented-only 8`
         by, gemm_t, gemm_f, gemm_b, n_gemm = instrumented_pass(model, trainer, batch, torch)
         achieved = gemm_f / (gemm_t * 1e-3) / 1e12
         traffic, traffic_src = pmc_hbm_bytes_per_gemm_launch(n_gemm)
@@ -527,15 +527,15 @@ def main(argv=None):
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                               "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gemm_b / max(n_gemm, 1),
-                              "kernel": "gemm_kernel<bf16,*>",
+                              "kernel": "gemm_kernel<bf16,*> + gemm_pp_kernel<*> (the MFMA contraction kernels: implicit-GEMM convs, linears)",
                               "launches_per_step": n_gemm, "algorithmic_gflop_per_step": gemm_f / 1e9, "kernel_ms_per_step": gemm_t,
                               # the same FLOPs over the WHOLE timed step (checkable against the driver's clock around the run):
                               # what the step sees, with every other kernel, the stream overlap and the host loop included
                               "whole_step_tflops": gemm_f / (result["ms_per_step"] * 1e-3) / 1e12,
                               "whole_step_frac": gemm_f / (result["ms_per_step"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                               # how this figure relates to the committed rocprofv3 summary of the same single-stream pass
-                              "rocprof_stats": "profiles/r3_kernel_stats_instrumented.csv = rocprofv3 --kernel-trace --stats of `bench.py --instrumented-only 8`; "
-                                               "profiles/r3_stats_vs_bench.txt: the event brackets read ~12 % longer than the kernel durations they enclose "
+                              "rocprof_stats": "profiles/r4_kernel_stats_instrumented.csv = rocprofv3 --kernel-trace --stats of `bench.py --instrumented-only 8`; "
+                                               "profiles/r4_stats_vs_bench.txt: the event brackets read ~12 % longer than the kernel durations they enclose "
                                                "(marker + dispatch latency of ~5 us per C-ABI call), so `achieved` is the conservative of the two"}
         result["breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 

@@ -7,11 +7,12 @@ prints them beside kernel_ms_per_pass of the bench line."""
 import csv, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 passes = int(sys.argv[2])
-fam = lambda n: ("gemm_kernel" in n) or ("splitk_reduce_kernel" in n) or ("splitk_finish_kernel" in n)
+gk = lambda n: ("gemm_kernel" in n) or ("gemm_pp_kernel" in n)
+fam = lambda n: gk(n) or ("splitk_reduce_kernel" in n) or ("splitk_finish_kernel" in n)
 tot = sum(float(r["TotalDurationNs"]) for r in rows if fam(r["Name"]))
 calls = sum(int(r["Calls"]) for r in rows if fam(r["Name"]))
-gem = sum(float(r["TotalDurationNs"]) for r in rows if "gemm_kernel" in r["Name"])
-gcalls = sum(int(r["Calls"]) for r in rows if "gemm_kernel" in r["Name"])
+gem = sum(float(r["TotalDurationNs"]) for r in rows if gk(r["Name"]))
+gcalls = sum(int(r["Calls"]) for r in rows if gk(r["Name"]))
 line = [l for l in open(sys.argv[3]).read().splitlines() if l.startswith("{")][-1]
 b = json.loads(line)
 ms = b.get("kernel_ms_per_pass_median") or b["roofline"]["kernel_ms_per_step"]
