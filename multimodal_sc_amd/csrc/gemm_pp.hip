@@ -347,90 +347,84 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   // phase 1 of the next tile's first K tile (or after the loop).  Epilogues with loads run BEFORE the phase's DMA (the compiler waits
   // vmcnt(0) for an ordinary load beside LDS-DMA: cdna_hip_programming.md §5 trap (b)), store-only epilogues AFTER it (their stores stay
   // in flight).  first / last / after_first: position of the K tile in its output tile (wave-uniform).
+  // Where a quadrant's epilogue runs: epilogues with loads in the READ part of the phase, before its DMA piece (above).  Store-only
+  // epilogues: group 0 in the read part behind the DMA piece, group 1 one barrier interval later, behind the MFMAs of the same phase —
+  // which is the interval of group 0's NEXT read part: the two waves of a SIMD then run their epilogue arithmetic (fc1: exact-erf GELU +
+  // derivative, as long as the K loop) side by side instead of one after the other, each stalling its partner at the barrier.
+  // Counted waits: XG0 / XG1 = quadrant epilogues whose stores are younger than the piece issued four phases ago, per group (group 1
+  // has not issued the current phase's stores yet when it waits).
+  // only where the epilogue arithmetic is long (GELU + derivative: -8 us on fc1); on the plain store epilogues the longer MFMA parts cost 4-5 us
+  // per launch (profiles/r4_pp_late_epilogue.txt); the 192- and 256-row tiles have no registers to spare for the longer live ranges
+  constexpr bool LATE = (EPI & PP_C2) != 0 && MI <= 5;
+  auto epi_read = [&](bool on, int m0, int n0, auto a_c, auto b_c, bool before_dma) __attribute__((always_inline)) {
+    if (on && (EP_LD ? before_dma : (!before_dma && (!LATE || wm == 0)))) {
+      if (!before_dma) __builtin_amdgcn_sched_barrier(0);
+      epilogue(m0, n0, a_c, b_c);
+      if (before_dma) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto epi_late = [&](bool on, int m0, int n0, auto a_c, auto b_c) __attribute__((always_inline)) {
+    if constexpr (LATE) {
+      if (on && wm == 1) epilogue(m0, n0, a_c, b_c);
+    }
+  };
+  auto wait2 = [&](auto xg0_c, auto xg1_c) __attribute__((always_inline)) {
+    if (!LATE || wm == 0) wait_phase(xg0_c); else wait_phase(xg1_c);
+  };
   auto ktile = [&](int kt, bool first, bool after_first, bool last_pair, bool last, auto u_c) __attribute__((always_inline)) {
     constexpr int U = decltype(u_c)::value;
+    constexpr bool U0 = U == 0, U1 = U == 1;
+    using XL = std::conditional_t<EP_LD, X3, X4>;       // (epilogues with loads sit BEFORE their phase's piece: one fewer is younger)
+    const bool e1 = U0 && first, e2 = U1 && last;
     // ---- phase 1
     read_b(U, S0{});
     read_a(U, S0{});
-    if constexpr (U == 0 && EP_LD) {
-      if (first) { epilogue(pm0, pn0, S1{}, S0{}); __builtin_amdgcn_sched_barrier(0); }
-    }
+    epi_read(e1, pm0, pn0, S1{}, S0{}, true);
     stage(kt + 1, U ^ 1, TB{}, S1{});
-    if constexpr (U == 0) {
-      if (first) {
-        if constexpr (!EP_LD) { __builtin_amdgcn_sched_barrier(0); epilogue(pm0, pn0, S1{}, S0{}); }
-        wait_phase(X4{});          // stores of (0,0) (0,1) (1,1) (1,0) are younger than the piece issued four phases ago
-      } else {
-        wait_phase(X0{});
-      }
-    } else {
-      // (1,0)'s stores of four phases ago are younger than that phase's piece only when the epilogue ran AFTER its DMA (store-only epilogues)
-      if (after_first && !EP_LD) wait_phase(X1{}); else wait_phase(X0{});
-    }
+    epi_read(e1, pm0, pn0, S1{}, S0{}, false);
+    if (e1) wait2(X4{}, X3{});
+    else if (U1 && after_first && !EP_LD) wait_phase(X1{});
+    else wait_phase(X0{});
     pp_barrier();
     mma(S0{}, S0{});
+    epi_late(e1, pm0, pn0, S1{}, S0{});
     pp_barrier();
     // ---- phase 2
     read_b(U, S1{});
-    if constexpr (U == 1) {
-      if (last) {
-        if constexpr (EP_LD) { epilogue(c_m0, c_n0, S0{}, S0{}); __builtin_amdgcn_sched_barrier(0); }
-        set_voffA(S1{}, n_m0);     // this half's DMA stream moves on to the next tile with the piece below
-      }
-    }
+    epi_read(e2, c_m0, c_n0, S0{}, S0{}, true);
+    if (e2) set_voffA(S1{}, n_m0);       // this half's DMA stream moves on to the next tile with the piece below
     stage(kt + 1, U ^ 1, TA{}, S1{});
-    if constexpr (U == 1) {
-      if (last) {
-        if constexpr (!EP_LD) { __builtin_amdgcn_sched_barrier(0); epilogue(c_m0, c_n0, S0{}, S0{}); }
-        wait_phase(X1{});
-      } else {
-        wait_phase(X0{});
-      }
-    } else {
-      if (first) wait_phase(std::conditional_t<EP_LD, X3, X4>{}); else wait_phase(X0{});
-    }
+    epi_read(e2, c_m0, c_n0, S0{}, S0{}, false);
+    if (e2) wait2(X1{}, X0{});
+    else if (e1) wait2(XL{}, X4{});
+    else wait_phase(X0{});
     pp_barrier();
     mma(S0{}, S1{});
+    epi_late(e2, c_m0, c_n0, S0{}, S0{});
     pp_barrier();
     // ---- phase 3
     read_a(U, S1{});
-    if constexpr (U == 1 && EP_LD) {
-      if (last) { epilogue(c_m0, c_n0, S0{}, S1{}); __builtin_amdgcn_sched_barrier(0); }
-    }
+    epi_read(e2, c_m0, c_n0, S0{}, S1{}, true);
     stage(kt + 2, U, TB{}, S0{});
-    if constexpr (U == 1) {
-      if (last) {
-        if constexpr (!EP_LD) { __builtin_amdgcn_sched_barrier(0); epilogue(c_m0, c_n0, S0{}, S1{}); }
-        wait_phase(X2{});
-      } else {
-        wait_phase(X0{});
-      }
-    } else {
-      if (first) wait_phase(std::conditional_t<EP_LD, X2, X3>{}); else wait_phase(X0{});
-    }
+    epi_read(e2, c_m0, c_n0, S0{}, S1{}, false);
+    if (e2) wait2(X2{}, X1{});
+    else if (e1) wait2(std::conditional_t<EP_LD, X2, X3>{}, X3{});
+    else wait_phase(X0{});
     pp_barrier();
     mma(S1{}, S1{});
+    epi_late(e2, c_m0, c_n0, S0{}, S1{});
     pp_barrier();
     // ---- phase 4
-    if constexpr (U == 1 && EP_LD) {
-      if (last) { epilogue(c_m0, c_n0, S1{}, S1{}); __builtin_amdgcn_sched_barrier(0); }
-    }
-    if constexpr (U == 0) {
-      if (last_pair) set_voffA(S0{}, n_m0);     // A0(s+2) is the next tile's from here on
-    }
+    epi_read(e2, c_m0, c_n0, S1{}, S1{}, true);
+    if (U0 && last_pair) set_voffA(S0{}, n_m0);  // A0(s+2) is the next tile's from here on
     stage(kt + 2, U, TA{}, S0{});
-    if constexpr (U == 1) {
-      if (last) {
-        if constexpr (!EP_LD) { __builtin_amdgcn_sched_barrier(0); epilogue(c_m0, c_n0, S1{}, S1{}); }
-        wait_phase(X3{});
-      } else {
-        wait_phase(X0{});
-      }
-    } else {
-      if (first) wait_phase(std::conditional_t<EP_LD, X1, X2>{}); else wait_phase(X0{});
-    }
+    epi_read(e2, c_m0, c_n0, S1{}, S1{}, false);
+    if (e2) wait2(X3{}, X2{});
+    else if (e1) wait2(std::conditional_t<EP_LD, X1, X2>{}, X2{});
+    else wait_phase(X0{});
     pp_barrier();
     mma(S1{}, S0{});
+    epi_late(e2, c_m0, c_n0, S1{}, S1{});
     pp_barrier();
   };
 

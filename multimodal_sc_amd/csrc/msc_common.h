@@ -108,9 +108,12 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats 
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 GEMM rounding): 1 exp + 1 rcp + 6 FMA instead of
 // the ~40-instruction libm erff — GELU sits in the epilogue of the widest GEMM of the transformer.
+// The reciprocal is the hardware's v_rcp_f32 (1 ulp): `__frcp_rn` expands to the correctly rounded division sequence (v_div_scale x2,
+// v_rcp, 4 FMA, v_div_fmas, v_div_fixup — 10 of the epilogue's 27 instructions per element, round 4), for a last bit of t that the
+// approximation's own 1.5e-7 swamps.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
   float y = fmaf(1.061405429f, t, -1.453152027f);
   y = fmaf(y, t, 1.421413741f);
   y = fmaf(y, t, -0.284496736f);
@@ -122,7 +125,7 @@ __device__ __forceinline__ float fast_erf(float x) {
 // gelu(x) and gelu'(x) = Phi(x) + x phi(x) from ONE erf evaluation: A&S 7.1.26 at x / sqrt(2) already holds exp(-x^2 / 2)
 __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
   const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
   float q = fmaf(1.061405429f, t, -1.453152027f);
   q = fmaf(q, t, 1.421413741f);
   q = fmaf(q, t, -0.284496736f);
