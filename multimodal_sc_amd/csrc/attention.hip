@@ -37,14 +37,6 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #else
 #define ATT_SB() ((void)0)
 #endif
-#ifndef ATT_DKV_KVLDS
-#define ATT_DKV_KVLDS 0    // 1 (experiment build): also compile the K/V-in-LDS, software-pipelined dK/dV variant and take it where T <= 320.
-                           // Measured (profiles/r3_attn_ablate.txt): correct, but 116-117 us per layer against 111 — the extra fragment
-                           // reads and 256 VGPRs cost more than the overlap of the two MFMA stages returns.  Not in the product build.
-#endif
-#ifndef ATT_DKV_PIPE
-#define ATT_DKV_PIPE 0     // 1 (experiment build): the two-accumulator-set software pipeline of the loop over the query tiles with K / V in registers
-#endif
 #ifndef ATT_BWD_OCC
 #define ATT_BWD_OCC 2      // waves per SIMD the backward kernels are compiled for (3 = 168 VGPRs spills both: 9 / 65 registers)
 #endif
@@ -331,18 +323,14 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dq_kernel(const bf1
 
 // ================================================================================================ backward: dK, dV
 // wave w owns key tiles w, w+nwaves, ...; Q and dO panels resident in LDS (rows + transposed reads).
-// KVLDS (T <= 320: four 40 KB panels = the whole 160 KB; the kernel's 222+ VGPRs allow one workgroup per CU anyway): the K and V panels
-// are staged too, each wave's K / V fragments come from LDS per query tile instead of living in 32 registers, and the freed registers
-// hold a second S' / dP' accumulator set: the loop over the query tiles is software-pipelined (see below).
-template <bool KVLDS>
+// (Rejected in round 3, removed from the source in round 4: K / V panels in LDS too with a second S' / dP' accumulator set and a software-
+// pipelined loop over the query tiles — correct, 116-117 us per layer against 111: profiles/r3_attn_ablate.txt.)
 __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int T, int Tpad, int H, float c_log2, float scale) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Qimg = smem;
   char* Gimg = smem + Tpad * 128;
-  char* Kimg = smem + 2 * Tpad * 128;     // KVLDS only
-  char* Vimg = smem + 3 * Tpad * 128;
   const int D = H * ATT_HD, ld = 3 * D;
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -357,10 +345,6 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
   if (ATT_ABLATE != 11) {
     stage_image<true>(Qimg, rsq, (uint32_t)b * (uint32_t)T * (uint32_t)ld + h * ATT_HD, ld, T, Tpad, nwaves);
     stage_image<true>(Gimg, rsg, (uint32_t)b * (uint32_t)T * (uint32_t)D + h * ATT_HD, D, T, Tpad, nwaves);
-    if constexpr (KVLDS) {
-      stage_image<true>(Kimg, rsq, (uint32_t)b * (uint32_t)T * (uint32_t)ld + D + h * ATT_HD, ld, T, Tpad, nwaves);
-      stage_image<true>(Vimg, rsq, (uint32_t)b * (uint32_t)T * (uint32_t)ld + 2 * D + h * ATT_HD, ld, T, Tpad, nwaves);
-    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -378,12 +362,10 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
     const bool kvld = krow < T;
     const long grow = (long)b * T + (kvld ? krow : 0);
     bfx8 kf[4], vf[4];
-    if constexpr (!KVLDS) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = frag_global(qkv + grow * ld + D + h * ATT_HD, 2 * ks + lh, kvld);
-        vf[ks] = frag_global(qkv + grow * ld + 2 * D + h * ATT_HD, 2 * ks + lh, kvld);
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag_global(qkv + grow * ld + D + h * ATT_HD, 2 * ks + lh, kvld);
+      vf[ks] = frag_global(qkv + grow * ld + 2 * D + h * ATT_HD, 2 * ks + lh, kvld);
     }
     f32x16_t dk[2], dv[2];
 #pragma unroll
@@ -423,13 +405,8 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ATT_ABLATE == 14) break;
-        if constexpr (KVLDS) {      // (rows >= T of the K / V images were staged as zeros, like the padded keys' register fragments)
-          s = MFMA(frag_rows(Qimg, qt * 32 + lr, 2 * ks + lh), frag_rows(Kimg, krow, 2 * ks + lh), s);
-          dp = MFMA(frag_rows(Gimg, qt * 32 + lr, 2 * ks + lh), frag_rows(Vimg, krow, 2 * ks + lh), dp);
-        } else {
-          s = MFMA(frag_rows(Qimg, qt * 32 + lr, 2 * ks + lh), kf[ks], s);     // S'[q][key] = S - lse / c
-          dp = MFMA(frag_rows(Gimg, qt * 32 + lr, 2 * ks + lh), vf[ks], dp);   // dP'[q][key] = dP - delta
-        }
+        s = MFMA(frag_rows(Qimg, qt * 32 + lr, 2 * ks + lh), kf[ks], s);     // S'[q][key] = S - lse / c
+        dp = MFMA(frag_rows(Gimg, qt * 32 + lr, 2 * ks + lh), vf[ks], dp);   // dP'[q][key] = dP - delta
       }
     };
     // stage 2 of tile qt: P and dS (in place), then dV += dO^T P and dK += Q^T dS
@@ -453,30 +430,6 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
         dk[dt] = MFMA(a1, e1, dk[dt]);
       }
     };
-    if constexpr (KVLDS || ATT_DKV_PIPE) {
-    // Software pipeline over the query tiles, two named accumulator sets: the S' / dP' products of tile qt+1 are in program order BEFORE
-    // the exponentials and the dV / dK products of tile qt, so the matrix pipe has independent work while the VALU finishes a tile
-    // (with two waves per SIMD nothing else covers the LDS-read -> MFMA -> exp -> transposed-read -> MFMA chain of one tile).
-    f32x16_t sA, dpA, sB, dpB;
-    float st0, st1, st2, st3;
-    stat_load(0, st0, st1);
-    stat_load(1, st2, st3);
-    stage1(0, st0, st1, sA, dpA);
-    for (int qt = 0; qt < NT; qt += 2) {
-      stat_load(qt + 2, st0, st1);
-      if (qt + 1 < NT) stage1(qt + 1, st2, st3, sB, dpB);
-      ATT_SB();
-      stage2(qt, sA, dpA);
-      ATT_SB();
-      if (qt + 1 < NT) {
-        stat_load(qt + 3, st2, st3);
-        if (qt + 2 < NT) stage1(qt + 2, st0, st1, sA, dpA);
-        ATT_SB();
-        stage2(qt + 1, sB, dpB);
-        ATT_SB();
-      }
-    }
-    } else {
     float nls_c, ndl_c, nls_n, ndl_n;
     stat_load(0, nls_c, ndl_c);
 #ifdef ATT_STAMP
@@ -528,7 +481,6 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf
       o[0] = seg0; o[1] = seg1; o[2] = seg2; o[3] = tl1 - tl0; o[4] = tp1 - tp0; o[5] = iters; o[6] = tp0;
     }
 #endif
-    }
     if (kvld) {
       store_rowT(dqkv + grow * ld + D + h * ATT_HD, dk, scale, lh);
       store_rowT(dqkv + grow * ld + 2 * D + h * ATT_HD, dv, 1.f, lh);
@@ -557,10 +509,7 @@ extern "C" int msc_attention_fwd(const void* qkv, void* o, float* lse, int B, in
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#if ATT_DKV_KVLDS
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#endif
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(64 * nw), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse, T, Tpad, H,
@@ -587,15 +536,7 @@ extern "C" int msc_attention_bwd(const void* qkv, const void* o, const void* dou
   const int nwq = nwq_env > 0 ? (nwq_env > 8 ? 8 : nwq_env) : nwb;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(64 * nwq), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                      delta, (bf16_t*)dqkv, T, Tpad, H, c, scale);
-#if ATT_DKV_KVLDS
-  static const int kvlds_env = getenv("MSC_ATT_DKV_KVLDS") ? atoi(getenv("MSC_ATT_DKV_KVLDS")) : 1;     // A/B knob of the experiment build
-  if (kvlds_env && (size_t)4 * Tpad * 128 <= 160 * 1024) {
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(B * H), dim3(64 * nwb), 2 * lds, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
-                       (bf16_t*)dqkv, T, Tpad, H, c, scale);
-    return msc_launch_status();
-  }
-#endif
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(B * H), dim3(64 * nwb), lds, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(64 * nwb), lds, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
                      (bf16_t*)dqkv, T, Tpad, H, c, scale);
   return msc_launch_status();
 }

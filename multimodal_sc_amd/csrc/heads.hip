@@ -132,13 +132,13 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const T* __restrict__ hea
 template <typename T>
 __global__ __launch_bounds__(256) void recon_loss_kernel(const T* __restrict__ recon, const float* __restrict__ img,
                                                          float* __restrict__ partial, T* __restrict__ drecon, int G, int P,
-                                                         float gscale) {
+                                                         float gscale, int vec_ok) {
   __shared__ float red[20];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int HW = G * P;
   const long per = (long)G * G * P * P * 3;
   float s = 0.f;
-  if ((P & 7) == 0) {
+  if (vec_ok) {                                               // host: P % 8 == 0 and 16-byte aligned recon / img / drecon
     const int gpr = P >> 3;                                   // 8-pixel groups per patch row
     const long ngrp = (long)G * G * P * gpr;                  // groups of this sample
     const long lo = ngrp * chunk / RL_CHUNKS, hi = ngrp * (chunk + 1) / RL_CHUNKS;
@@ -339,10 +339,13 @@ extern "C" int msc_recon_loss(const void* recon, const float* img_nchw, float* s
   MSC_CHECK_ARG(recon && img_nchw && sse && ws && B > 0 && G > 0 && P > 0);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(RL_CHUNKS, (unsigned)B);
+  // the 8-pixel vector path does 16-byte loads / stores of all three tensors: a caller's image view at a 4-byte storage offset (eager
+  // mode hands the user's tensor over as it is) takes the element-wise loop instead
+  const int vec_ok = P % 8 == 0 && (((uintptr_t)recon | (uintptr_t)img_nchw | (uintptr_t)drecon) & 15) == 0;
   if (dtype == MSC_F32)
-    hipLaunchKernelGGL(recon_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)recon, img_nchw, ws, (float*)drecon, G, P, gscale);
+    hipLaunchKernelGGL(recon_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)recon, img_nchw, ws, (float*)drecon, G, P, gscale, vec_ok);
   else if (dtype == MSC_BF16)
-    hipLaunchKernelGGL(recon_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)recon, img_nchw, ws, (bf16_t*)drecon, G, P, gscale);
+    hipLaunchKernelGGL(recon_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)recon, img_nchw, ws, (bf16_t*)drecon, G, P, gscale, vec_ok);
   else
     return MSC_ERR_BAD_ARG;
   hipLaunchKernelGGL(recon_loss_finalize_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, ws, sse, B);

@@ -31,6 +31,7 @@ would be latency-bound per link.  MSC_DP_OVERLAP=0 falls back to one non-overlap
 """
 from __future__ import annotations
 
+import collections
 import os
 import warnings
 
@@ -115,6 +116,8 @@ def _flatten(batch, prefix=""):
 
 
 class Trainer:
+    MAX_PROGRAMS = 8          # recorded launch lists kept (least recently used dropped)
+
     def __init__(self, model: MultimodalSC, lr: float = 1e-4, n_buckets: int = 4, use_ppo: bool = True):
         self.model = model
         self.lr = lr
@@ -148,7 +151,12 @@ class Trainer:
                 h = L.query("msc_stream_create", int(os.environ["MSC_MAIN_PRIO"]))
             self._main = torch.cuda.ExternalStream(h, device=model.rt.device)
         self._arena = None        # runtime.Arena of this trainer's steps (replay mode)
-        self._programs = {}       # batch signature -> {"seen": eager steps so far, "prog": Program, "static": batch, "terms": ...}
+        # (batch signature, lr, loss mode) -> {"seen": eager steps so far, "prog": Program, "static": batch, "terms": ...}; least recently
+        # used first, at most MAX_PROGRAMS entries: the learning rate is a baked argument of the recorded optimizer launch, so a per-step
+        # schedule makes a new key every step — those never reach a recording (the step stays eager, said once) and must not pile up;
+        # a piecewise schedule keeps its few programs, each pinning its own ~55 MB input clone
+        self._programs = collections.OrderedDict()
+        self._lru_warned = False
         self._rec = None          # active Recorder while a step is being recorded
         self.exchange = None      # GradExchange, built on the first multi-rank step (needs the model's mid offset)
         self._seen = 0
@@ -257,6 +265,14 @@ class Trainer:
         st = self._programs.get(key)
         if st is None:
             st = self._programs[key] = {"seen": 0, "prog": None, "static": None, "terms": None}
+            while len(self._programs) > self.MAX_PROGRAMS:
+                _, old = self._programs.popitem(last=False)      # the Program's destructor frees the C-side list and its kept tensors
+                if old["prog"] is None and not self._lru_warned:
+                    self._lru_warned = True
+                    warnings.warn("launch replay: a (batch shape, learning rate, loss mode) key was dropped before it was recorded — with a "
+                                  "learning rate that changes every step the trainer stays on the eager host loop", RuntimeWarning)
+        else:
+            self._programs.move_to_end(key)
         if self._arena is None:
             self._arena = Arena(rt.device)
         if st["prog"] is not None:

@@ -1030,6 +1030,16 @@ def test_recon_loss_psnr(rts, dtype, G, P):
     check("unpatchify", out_img, rec, 0.0)
     dref = 0.25 * (rec - img).view(B, 3, G, P, G, P).permute(0, 2, 4, 3, 5, 1).reshape(B * G * G, P * P * 3)
     check("drecon", dp, dref, tol(dtype))
+    # the caller's image as a contiguous view at a 4-byte storage offset (eager mode passes the user's tensor as it is): the 16-byte vector
+    # path must not be taken on it — same results through the element-wise loop
+    store = torch.empty(img.numel() + 1, device=rt.device)
+    img_off = store[1:].view_as(img)
+    img_off.copy_(img)
+    assert img_off.data_ptr() % 16 == 4 and img_off.is_contiguous()
+    sse_o, dp_o = rt.f32(B), torch.empty_like(pd)
+    rt.call("msc_recon_loss", pd, img_off, sse_o, dp_o, ws, B, G, P, 0.25, rt.dt)
+    check("sse, image at a 4-byte offset", sse_o, sse_ref, 1e-5)
+    check("drecon, image at a 4-byte offset", dp_o, dref, tol(dtype))
     # PSNR known answers: uniform error eps -> 20 log10(1/eps)
     eps = 0.1
     pat2 = (img + eps).view(B, 3, G, P, G, P).permute(0, 2, 4, 3, 5, 1).reshape(B * G * G, P * P * 3)

@@ -548,9 +548,10 @@ def test_launch_replay_matches_eager(cuda, monkeypatch, name, B, chains):
             sse.append(terms["sse"].clone())
         torch.cuda.synchronize()
         if mode == "1":
-            progs = [st["prog"] for st in tr._programs.values()]
-            assert len(progs) == 2 and progs[0] is not None, "the launch list was not recorded"
-            assert progs[0].count() > 100
+            progs = [st["prog"] for st in tr._programs.values()]      # least recently used first: the one-off shape, then the replayed one
+            rec = [p for p in progs if p is not None]
+            assert len(progs) == 2 and len(rec) == 1, "the launch list was not recorded"
+            assert rec[0].count() > 100
         res[mode] = (m.params.P.clone(), m.params.M.clone(), m.params.V.clone(), sse)
     for a, b in zip(res["0"][:3], res["1"][:3]):
         assert torch.equal(a, b)
@@ -590,6 +591,37 @@ def test_launch_replay_recorded_from_a_clean_side_stream(cuda, monkeypatch):
         res[mode] = (m.params.P.clone(), m.params.M.clone(), m.params.V.clone())
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
+
+
+def test_launch_replay_programs_are_bounded_under_a_per_step_schedule(cuda, monkeypatch):
+    """The learning rate is a baked argument of the recorded optimizer launch: a schedule that changes it every step makes a new program
+    key every step.  Those keys never reach a recording; the trainer must stay on the eager loop, keep at most MAX_PROGRAMS entries and
+    say so once (round-3 advisor finding on Trainer._programs)."""
+    import warnings
+    from multimodal_sc_amd.model import MultimodalSC, named_config
+    from multimodal_sc_amd.trainer import Trainer
+    from oracle import model as O
+    monkeypatch.setenv("MSC_REPLAY", "1")
+    batch = _to("cuda:0", O.synthetic_batch(O.named_config("C0"), 2, seed=5))
+    batch["noise"] = batch["fading"] = None
+    m = MultimodalSC(named_config("C0"), dtype="bf16", device="cuda:0", seed=3)
+    tr = Trainer(m, lr=1e-3)
+    monkeypatch.setattr(Trainer, "MAX_PROGRAMS", 3)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for i in range(7):
+            tr.lr = 1e-3 * (1.0 - 0.1 * i)
+            tr.step(batch)
+    torch.cuda.synchronize()
+    assert len(tr._programs) <= 3
+    assert all(st["prog"] is None for st in tr._programs.values())
+    assert sum("launch replay" in str(w.message) for w in seen) == 1
+    # a constant rate afterwards records and replays as usual, and the oldest entries make room for it
+    for _ in range(4):
+        tr.step(batch)
+    torch.cuda.synchronize()
+    assert len(tr._programs) <= 3 and any(st["prog"] is not None for st in tr._programs.values())
+    assert torch.isfinite(m.params.P).all()
 
 
 def test_hipgraph_replay_matches_eager(cuda, monkeypatch):
