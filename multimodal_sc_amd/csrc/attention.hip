@@ -131,6 +131,7 @@ __device__ __forceinline__ void store_rowT(bf16_t* rowptr, const f32x16_t (&acc)
 // grid = B*H, block = 64 * ceil(NT/2) threads; wave w owns query tiles 2w and 2w+1 and sweeps all key tiles.
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                         int T, int Tpad, int H, float c_log2) {
+  MSC_BOOST();
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Kimg = smem;
   char* Vimg = smem + Tpad * 128;
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dq_kernel(const bf1
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, bf16_t* __restrict__ dqkv, int T, int Tpad,
                                                            int H, float c_log2, float scale) {
+  MSC_BOOST();
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Kimg = smem;                 // dual use: rows for S^T, transposed for dQ
   char* Vimg = smem + Tpad * 128;    // rows only (dP^T), staged with the row swizzle
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dq_kernel(const bf1
 __global__ __launch_bounds__(512, ATT_BWD_OCC) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int T, int Tpad, int H, float c_log2, float scale) {
+  MSC_BOOST();
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Qimg = smem;
   char* Gimg = smem + Tpad * 128;

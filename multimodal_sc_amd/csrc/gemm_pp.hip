@@ -89,6 +89,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   static_assert(NIA1 == 8 || NIA1 == 12 || NIA1 == 16, "A piece: 8, 12 or 16 DMA instructions");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
 
+  MSC_BOOST();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;            // wm = ping-pong group
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   auto mma = [&](auto a_c, auto b_c) __attribute__((always_inline)) {
     constexpr int Ah = decltype(a_c)::value, Bh = decltype(b_c)::value;
     constexpr int MFS = Ah ? MF1 : MF0, MB = Ah ? MF0 : 0;
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(MSC_BOOST_LEVEL ? 3 : 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[2 * Bh + j][MB + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[Bh][j][s], fa[f][s], acc[2 * Bh + j][MB + f], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(MSC_BOOST_LEVEL);
   };
 
   // ---- epilogue of quadrant (a, b) of the tile at (m0, n0): lane = row lr of each 16-row fragment, 8 consecutive columns; the
@@ -237,6 +238,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const uint32_t ldc2 = (uint32_t)p.ldc * 2u;
   const int ep_row = wm * (16 * MI) + lr;                                                    // row inside the tile (+ 16 per fragment)
   const uint32_t ep_lane_off = (uint32_t)ep_row * ldc2 + (uint32_t)(wn * 64 + 8 * lg) * 2u; // bytes from the tile's first element
+  // Epilogue operands read from memory (residual / stored activation derivative): an ordinary load inside the epilogue costs a full
+  // drain of the vector-memory queue (the compiler waits vmcnt(0) for it beside LDS-DMA) and, inside the training step, the latency of
+  // HBM — the 80 MB derivative tensor of fc2's dgrad is cold there: 95 us per launch against 64 from a warm cache, round 4.  PREF: the
+  // tile's 2 * MI 16-byte loads are issued as inline assembly (the compiler does not wait for what it does not know) in phase 1 of the
+  // tile's SECOND-TO-LAST K tile, five phases before the first quadrant epilogue; the counted waits order them like any DMA piece: they
+  // are older than that phase's piece, so the wait of phase 1 of the last K tile ("everything older than the four youngest pieces") is
+  // also the wait for them, and the four waits in between allow them in flight (+NPRE).  40 registers at MI = 5; the 192- and 256-row
+  // tiles have none to spare and keep the in-epilogue loads.
+  constexpr bool PREF = (EPI & (PP_RES | PP_DREF)) != 0 && MI <= 5;
+  constexpr int NPRE = PREF ? 2 * MI : 0;
+  pp_u32x4 pre[2][PREF ? MI : 1];
+  auto prefetch = [&](int m0, int n0) __attribute__((always_inline)) {
+    if constexpr (PREF) {
+      const uint64_t base = (uint64_t)((EPI & PP_DREF) ? p.dref : p.res);
+      const pp_u32x4 dsc = {(uint32_t)base, (uint32_t)(base >> 32) & 0xffffu, 0x7ffffff0u, 0x00020000u};
+      const int rows_left = p.M - m0;
+#pragma unroll
+      for (int bh = 0; bh < 2; ++bh) {
+        const uint32_t tile_off = (uint32_t)m0 * ldc2 + (uint32_t)(n0 + bh * 32) * 2u;
+#pragma unroll
+        for (int f = 0; f < MI; ++f) {
+          const uint32_t off = (ep_row + f * 16 < rows_left) ? ep_lane_off + (tile_off + (uint32_t)(f * 16) * ldc2) : PP_OOB;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pre[bh][f]) : "v"(off), "s"(dsc) : "memory");
+        }
+      }
+    }
+  };
   auto epilogue = [&](int m0, int n0, auto a_c, auto b_c) __attribute__((always_inline)) {
     constexpr int Ah = decltype(a_c)::value, Bh = decltype(b_c)::value;
     constexpr int MFS = Ah ? MF1 : MF0, MB = Ah ? MF0 : 0;
@@ -280,14 +308,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         }
       }
       if constexpr (EPI & PP_RES) {
-        const pp_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsR, off, 0, 0);
+        pp_u32x4 r;
+        if constexpr (PREF) r = pre[Bh][MB + f]; else r = __builtin_amdgcn_raw_buffer_load_b128(rsR, off, 0, 0);
         float rv[8];
         pp_unpack8(r, rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
       }
       if constexpr (EPI & PP_DREF) {
-        const pp_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0);
+        pp_u32x4 r;
+        if constexpr (PREF) r = pre[Bh][MB + f]; else r = __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0);
         float rv[8];
         pp_unpack8(r, rv);
 #pragma unroll
@@ -302,20 +332,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   };
   // vector-memory instructions one fragment of an epilogue issues and leaves in flight (its loads are consumed inside): the stores
   constexpr int EP_ST = 1 + ((EPI & PP_C2) ? 1 : 0);
-  constexpr bool EP_LD = (EPI & (PP_RES | PP_DREF)) != 0;
+  constexpr bool EP_LD = (EPI & (PP_RES | PP_DREF)) != 0 && !PREF;     // epilogues that still load inside
   constexpr int MFN = MF0 < MF1 ? MF0 : MF1;          // (counting the smaller half for every quadrant only makes a wait stricter)
 
   // Counted wait of a phase, after its DMA piece was issued: everything older than the FOUR youngest pieces has landed — the piece
   // issued four phases ago is the one the NEXT phase reads ("read a staged buffer one phase after the wait that retires it").  XQ:
   // epilogue stores (in quadrant-epilogue units) known to be younger than that piece; they may stay in flight too.
-  auto wait_phase = [&](auto xq_c) __attribute__((always_inline)) {
-    constexpr int X = decltype(xq_c)::value * MFN * EP_ST;
+  auto wait_phase_n = [&](auto x_c) __attribute__((always_inline)) {
+    constexpr int X = decltype(x_c)::value;
     if constexpr (INFL_G0 == INFL_G1) {
       pp_wait_vm<INFL_G0 + X>();
     } else {
       if (wm == 0) pp_wait_vm<INFL_G0 + X>();
       else pp_wait_vm<INFL_G1 + X>();
     }
+  };
+  auto wait_phase = [&](auto xq_c) __attribute__((always_inline)) {
+    wait_phase_n(std::integral_constant<int, decltype(xq_c)::value * MFN * EP_ST>{});
+  };
+  // steady-state wait of a phase; `pf`: this K tile is the one whose phase 1 issued the epilogue operand prefetch (they stay in flight)
+  auto wait_steady = [&](bool pf) __attribute__((always_inline)) {
+    if (PREF && pf) wait_phase_n(std::integral_constant<int, NPRE>{});
+    else wait_phase_n(std::integral_constant<int, 0>{});
   };
   using X0 = std::integral_constant<int, 0>;
   using X1 = std::integral_constant<int, 1>;
@@ -376,15 +414,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     constexpr bool U0 = U == 0, U1 = U == 1;
     using XL = std::conditional_t<EP_LD, X3, X4>;       // (epilogues with loads sit BEFORE their phase's piece: one fewer is younger)
     const bool e1 = U0 && first, e2 = U1 && last;
+    const bool pf = U0 && last_pair;     // the tile's second-to-last K tile (never its first: K >= 256 = 4 K tiles)
     // ---- phase 1
     read_b(U, S0{});
     read_a(U, S0{});
     epi_read(e1, pm0, pn0, S1{}, S0{}, true);
+    if (PREF && pf) prefetch(c_m0, c_n0);
     stage(kt + 1, U ^ 1, TB{}, S1{});
     epi_read(e1, pm0, pn0, S1{}, S0{}, false);
     if (e1) wait2(X4{}, X3{});
     else if (U1 && after_first && !EP_LD) wait_phase(X1{});
-    else wait_phase(X0{});
+    else wait_steady(pf);
     pp_barrier();
     mma(S0{}, S0{});
     epi_late(e1, pm0, pn0, S1{}, S0{});
@@ -397,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     epi_read(e2, c_m0, c_n0, S0{}, S0{}, false);
     if (e2) wait2(X1{}, X0{});
     else if (e1) wait2(XL{}, X4{});
-    else wait_phase(X0{});
+    else wait_steady(pf);
     pp_barrier();
     mma(S0{}, S1{});
     epi_late(e2, c_m0, c_n0, S0{}, S0{});
@@ -409,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     epi_read(e2, c_m0, c_n0, S0{}, S1{}, false);
     if (e2) wait2(X2{}, X1{});
     else if (e1) wait2(std::conditional_t<EP_LD, X2, X3>{}, X3{});
-    else wait_phase(X0{});
+    else wait_steady(pf);
     pp_barrier();
     mma(S1{}, S1{});
     epi_late(e2, c_m0, c_n0, S0{}, S1{});
@@ -421,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     epi_read(e2, c_m0, c_n0, S1{}, S1{}, false);
     if (e2) wait2(X3{}, X2{});
     else if (e1) wait2(std::conditional_t<EP_LD, X1, X2>{}, X2{});
-    else wait_phase(X0{});
+    else wait_steady(pf);
     pp_barrier();
     mma(S1{}, S0{});
     epi_late(e2, c_m0, c_n0, S1{}, S1{});

@@ -14,6 +14,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define MSC_WAVE 64
 
+// Wave priority of the kernels that sit on the step's critical chain (memory-bound normalisation passes, attention, the ping-pong
+// contraction): their waves share SIMDs with the side stream's weight-gradient GEMMs, and the instruction arbiter serves the higher
+// s_setprio level first.  0 = off.  Measured same-box (profiles/r4_epilogue_prefetch_and_priority.txt): 7.320 / 7.321 ms per step at
+// level 2 against 7.334 / 7.347 at 0 — the contention is mostly about register-file residency (a weight-gradient workgroup holds its
+// registers for 50-140 us whatever its priority), so the gain is small; kept because it is free.
+#ifndef MSC_BOOST_LEVEL
+#define MSC_BOOST_LEVEL 2
+#endif
+#define MSC_BOOST() do { if (MSC_BOOST_LEVEL) __builtin_amdgcn_s_setprio(MSC_BOOST_LEVEL); } while (0)
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }

@@ -102,6 +102,7 @@ template <int VEC> __device__ __forceinline__ void ldc(const float* __restrict__
 template <typename T, int UN>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const T* __restrict__ res, T* __restrict__ y, long nvec, int C, int relu) {
+  MSC_BOOST();
   constexpr int VEC = msc_traits<T>::VEC;
   const unsigned ncv = (unsigned)C / VEC;
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ partial,
                                                             long rows, int C, int relu, int rows_per_block) {
+  MSC_BOOST();
   constexpr int VEC = msc_traits<T>::VEC;
   const int ncx = C / VEC;          // threads across channels
   const int nty = 256 / ncx;        // rows handled concurrently
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ shift, const float* __restrict__ sum_dz,
                                                            const float* __restrict__ sum_dzx, T* __restrict__ dx, T* __restrict__ dres,
                                                            long nvec, int C, int relu, float inv_rows) {
+  MSC_BOOST();
   constexpr int VEC = msc_traits<T>::VEC;
   const bool xmask = relu && scale != nullptr;
   const bool ymask = relu && scale == nullptr;
@@ -472,6 +475,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows,
                                                      int D, float eps) {
+  MSC_BOOST();
   constexpr int VEC = msc_traits<T>::VEC;
   constexpr int MAXIT = LN_MAXC / VEC;
   constexpr int R = LN_FWD_ROWS;
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ dadd,
                                                      T* __restrict__ dx, float* __restrict__ partial, long rows, int D) {
+  MSC_BOOST();
   constexpr int VEC = msc_traits<T>::VEC;
   constexpr int MAXIT = LN_MAXC / VEC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

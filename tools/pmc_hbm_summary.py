@@ -12,7 +12,7 @@ def load(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0][:70]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:70]
         tot[k] += float(r["Counter_Value"]) * 1024.0
         dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         calls[k] += 1

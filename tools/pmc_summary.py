@@ -10,7 +10,7 @@ dur = collections.defaultdict(float)
 calls = collections.Counter()
 seen = set()
 for r in rows:
-    k = r["Kernel_Name"].split("(")[0][:70]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:70]
     val[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Dispatch_Id"] not in seen:
         seen.add(r["Dispatch_Id"])
