@@ -1127,6 +1127,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 // gemm_pp.hip
 int msc_pp_tile_rows(const GemmParams& p, int ncu);
 int msc_pp_launch(const GemmParams& p, int ncu, hipStream_t st);
+bool msc_skinny_ok(const GemmParams& p);                    // gemm_skinny.hip: dense bf16 linears of at most 64 rows
+int msc_skinny_launch(const GemmParams& p, hipStream_t st);
 // the most recent contraction launch of this process, for tests that assert which kernel variant a shape took (msc_debug_last_gemm):
 // kind (1 one tile per workgroup, 2 persistent 256-row, 3 ping-pong), bm, bn, threads, K slices, xcd_split, cls_interleave, extended epilogue
 static int g_last_gemm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1190,6 +1192,10 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   if (zs > 65535) return MSC_ERR_UNSUPPORTED;
   // dense bf16 linears (both operands k-major, one launch over the whole matrix): the persistent ping-pong kernel of gemm_pp.hip
   if constexpr (DT == MSC_BF16 && AMODE == OPM_DENSE_K && BMODE == OPM_DENSE_K && EPX != 2) {
+    if (batch == 1 && msc_skinny_ok(p)) {     // one row per frame (codec, heads, state encoder): no staging, one memory round trip
+      note_gemm(4, 64, 16, p.K >= 2048 ? 512 : 256, 1, 0, 0, EPX);
+      return msc_skinny_launch(p, st);
+    }
     if (batch == 1 && msc_pp_tile_rows(p, num_cus())) {
       note_gemm(3, msc_pp_tile_rows(p, num_cus()), 256, 512, 1, 0, 0, EPX);
       return msc_pp_launch(p, num_cus(), st);

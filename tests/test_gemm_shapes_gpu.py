@@ -311,3 +311,67 @@ def test_conv_forced_128x128(rt, knob, case):
     info = last_gemm()
     assert info[0] == 1 and info[2] == 128, info                     # (the row tile is capped at 64 where a parity class asks for it)
     check("dx", dx, xq.grad, 2.4e-2)
+
+
+# ------------------------------------------------------------------------------------------------ one row per frame: the skinny kernel
+# (name, out features, in features, activation): the codec / head / state-encoder layers of C3 (model.py param_specs)
+SKINNY_FWD = [("enc.fc1 relu", 256, 512, "relu"), ("head.fc tanh", 256, 512, "tanh"), ("head.out", 16, 256, "none"),
+              ("recon.fc1 relu", 3136, 512, "relu"), ("state.fc1 relu", 512, 32, "relu"), ("dec.fc2", 512, 256, "none"), ("sigmoid", 48, 64, "sigmoid")]
+_ACT = {"none": 0, "relu": 1, "tanh": 3, "sigmoid": 4}
+_ACT_REF = {"none": lambda t: t, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+
+
+@pytest.mark.parametrize("rows", [64, 32, 33, 7, 1])
+@pytest.mark.parametrize("name,N,K,act", SKINNY_FWD)
+def test_skinny_linear_forward(rt, knob, name, N, K, act, rows):
+    """forward of the <= 64-row dense layers on gemm_skinny.hip (no staging; the K split over the waves summed in wave order) against fp32
+    PyTorch from the bf16-rounded inputs, against the tiled family on the same inputs, and bit-identical when repeated"""
+    x, w, b = rnd(rows, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
+    r = rnd(rows, N, seed=4) if "dec" in name else None
+    ref = _ACT_REF[act](qb(x) @ qb(w).t() + b) + (qb(r) if r is not None else 0)
+    xd, wd, bd, rd = dev(x, rt), dev(w, rt), b.to(rt.device), (dev(r, rt) if r is not None else None)
+    outs = {}
+    for sk in (1, 0):
+        knob("gemm_skinny", sk)
+        y = torch.full((rows, N), float("nan"), device=rt.device, dtype=rt.tdtype)
+        rt.call("msc_linear_fwd", xd, wd, bd, rd, y, None, rows, N, K, _ACT[act], rt.dt)
+        info = last_gemm()
+        assert (info[0] == 4) == bool(sk), info
+        check(f"y skinny={sk}", y, ref, 1.2e-2)
+        outs[sk] = y
+    check("skinny vs tiled", outs[1], outs[0].float(), 1.2e-2)
+    knob("gemm_skinny", 1)
+    y2 = torch.empty_like(outs[1])
+    rt.call("msc_linear_fwd", xd, wd, bd, rd, y2, None, rows, N, K, _ACT[act], rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, outs[1])
+
+
+@pytest.mark.parametrize("rows", [64, 33, 2])
+@pytest.mark.parametrize("name,N,K,dact,res", [("recon.fc1 dgrad + head branch", 3136, 512, "none", True), ("head.out dgrad x tanh'", 16, 256, "tanh", False),
+                                               ("dec.fc2 dgrad x relu'", 512, 256, "relu", False), ("enc.fc1 dgrad", 256, 512, "none", False)])
+def test_skinny_linear_dgrad(rt, knob, name, N, K, dact, res, rows):
+    """data gradients of the same layers: dx[M,K] = dy[M,N] wt[K,N]^T (+ residual) x act'(ref) — the reduction runs over N (3136 for the
+    reconstruction head: eight waves share it)"""
+    dy, w = rnd(rows, N, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(N))
+    wt = qb(w).t().contiguous()                     # [K][N]
+    r = rnd(rows, K, seed=3) if res else None
+    yref = torch.tanh(rnd(rows, K, seed=5)) if dact == "tanh" else torch.relu(rnd(rows, K, seed=5)) if dact == "relu" else None
+    ref = qb(dy) @ qb(w) + (qb(r) if res else 0)
+    if dact == "tanh":
+        ref = ref * (1 - qb(yref) ** 2)
+    elif dact == "relu":
+        ref = ref * (qb(yref) > 0)
+    outs = {}
+    for sk in (1, 0):
+        knob("gemm_skinny", sk)
+        dx = torch.full((rows, K), float("nan"), device=rt.device, dtype=rt.tdtype)
+        rt.call("msc_linear_dgrad", dev(dy, rt), dev(wt, rt), dev(r, rt) if res else None, dev(yref, rt) if yref is not None else None,
+                _ACT[dact], None, dx, rows, N, K, rt.dt)
+        info = last_gemm()
+        assert (info[0] == 4) == bool(sk), info
+        if sk:
+            assert info[3] == (512 if N >= 2048 else 256), info
+        check(f"dx skinny={sk}", dx, ref, 1.2e-2)
+        outs[sk] = dx
+    check("skinny vs tiled", outs[1], outs[0].float(), 1.2e-2)
