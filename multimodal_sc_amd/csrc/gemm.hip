@@ -1127,6 +1127,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 // gemm_pp.hip
 int msc_pp_tile_rows(const GemmParams& p, int ncu);
 int msc_pp_launch(const GemmParams& p, int ncu, hipStream_t st);
+bool msc_conv_c64_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype);      // conv_c64.hip: ResNet layer 1
+int msc_conv_c64_launch(const void* x, const void* w, void* y, const void* res, const void* relu_ref, float* part, int part_rows, int B, int H,
+                        int flip, int ncu, hipStream_t st);
 bool msc_skinny_ok(const GemmParams& p);                    // gemm_skinny.hip: dense bf16 linears of at most 64 rows
 int msc_skinny_launch(const GemmParams& p, hipStream_t st);
 // the most recent contraction launch of this process, for tests that assert which kernel variant a shape took (msc_debug_last_gemm):
@@ -1347,6 +1350,11 @@ extern "C" int msc_conv2d_fwd(const void* x, const void* w, void* y, float* bn_p
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   MSC_CHECK_ARG(Ho > 0 && Wo > 0);
   if (!fits32((long)B * H * W * Cin, dtype) || !fits32((long)Cout * KH * KW * Cin, dtype)) return MSC_ERR_UNSUPPORTED;
+  if (msc_conv_c64_ok(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype)) {      // ResNet layer 1: halo resident in LDS, weights in registers
+    note_gemm(5, 224, 64, 256, 1, 0, 0, 0);
+    return msc_conv_c64_launch(x, w, y, nullptr, nullptr, bn_partial, bn_partial ? (int)msc_conv2d_fwd_stat_rows((int64_t)B * Ho * Wo, Cout, dtype) : 0, B, H,
+                               0, num_cus(), (hipStream_t)stream);
+  }
   GemmParams p = base_params();
   p.A = x; p.B = w; p.C = y; p.stats = bn_partial;
   p.M = B * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin;
@@ -1399,6 +1407,10 @@ static int conv2d_dgrad_impl(const void* dy, const void* wt, const void* res, co
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   MSC_CHECK_ARG(Ho > 0 && Wo > 0);
   if (!fits32((long)B * Ho * Wo * Cout, dtype) || !fits32((long)Cout * KH * KW * Cin, dtype)) return MSC_ERR_UNSUPPORTED;
+  if (!bn_x && msc_conv_c64_ok(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype)) {      // the same kernel on the transposed weights, taps negated
+    note_gemm(5, 224, 64, 256, 1, 0, 0, relu_ref ? 1 : 0);
+    return msc_conv_c64_launch(dy, wt, dx, res, relu_ref, nullptr, 0, B, H, 1, num_cus(), (hipStream_t)stream);
+  }
   GemmParams p = base_params();
   p.A = dy; p.B = wt; p.C = dx; p.res = res;
   p.M = B * H * W; p.N = Cin; p.K = KH * KW * Cout;

@@ -375,3 +375,91 @@ def test_skinny_linear_dgrad(rt, knob, name, N, K, dact, res, rows):
         check(f"dx skinny={sk}", dx, ref, 1.2e-2)
         outs[sk] = dx
     check("skinny vs tiled", outs[1], outs[0].float(), 1.2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ ResNet layer 1: the halo-resident 64 -> 64 kernel
+@pytest.mark.parametrize("Bc,Hc", [(2, 56), (1, 4), (3, 12), (5, 8)])
+def test_conv_c64_forward_and_statistics(rt, knob, Bc, Hc):
+    """3x3 / stride 1 / pad 1, 64 -> 64 channels on 56-wide maps through conv_c64.hip (halo in LDS, weights in registers): output and the
+    BatchNorm partial sums against fp32 PyTorch from bf16-rounded inputs, against the implicit-GEMM kernel, bit-identical when repeated.
+    Heights 4 / 8 / 12: every tile touches the top or bottom zero padding, and with 5 images the tile count is odd."""
+    from multimodal_sc_amd import lib as L
+    Wc, C = 56, 64
+    x = rnd(Bc, Hc, Wc, C, seed=1)
+    w = rnd(C, 3, 3, C, seed=2, scale=1 / math.sqrt(9 * C))
+    ref = TF.conv2d(qb(x).permute(0, 3, 1, 2), qb(w).permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+    Mrows = Bc * Hc * Wc
+    nblk = L.query("msc_conv2d_fwd_stat_rows", Mrows, C, rt.dt)
+    xd, wd = dev(x, rt), dev(w, rt)
+    outs = {}
+    for on in (1, 0):
+        knob("conv_c64", on)
+        y = torch.full((Bc, Hc, Wc, C), float("nan"), device=rt.device, dtype=rt.tdtype)
+        part = torch.full((nblk, 2, C), float("nan"), device=rt.device)
+        rt.call("msc_conv2d_fwd", xd, wd, y, part, Bc, Hc, Wc, C, C, 3, 3, 1, 1, None, 0, rt.dt)
+        info = last_gemm()
+        assert (info[0] == 5) == bool(on), info
+        check(f"y c64={on}", y, ref, 1.2e-2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        s = part.double().sum(0).cpu()
+        flat = ref.reshape(-1, C).double()
+        assert (s[0] - flat.sum(0)).abs().max() <= 2e-3 * max(1.0, flat.abs().sum(0).max().item())
+        assert (s[1] - (flat * flat).sum(0)).abs().max() <= 2e-3 * max(1.0, (flat * flat).sum(0).max().item())
+        outs[on] = (y, part.clone())
+    check("c64 vs implicit GEMM", outs[1][0], outs[0][0].float(), 1.2e-2)
+    knob("conv_c64", 1)
+    y2, part2 = torch.empty_like(outs[1][0]), torch.empty_like(outs[1][1])
+    rt.call("msc_conv2d_fwd", xd, wd, y2, part2, Bc, Hc, Wc, C, C, 3, 3, 1, 1, None, 0, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, outs[1][0]) and torch.equal(part2, outs[1][1])
+
+
+@pytest.mark.parametrize("mode", ["plain", "res", "res+relu"])
+@pytest.mark.parametrize("Bc,Hc", [(2, 56), (3, 8)])
+def test_conv_c64_dgrad(rt, knob, Bc, Hc, mode):
+    """data gradient of the same convolution (transposed weight layout, taps negated), with the residual add and the ReLU mask of the
+    epilogue, against the autograd gradient of fp32 PyTorch"""
+    Wc, C = 56, 64
+    dy = rnd(Bc, Hc, Wc, C, seed=1)
+    w = rnd(C, 3, 3, C, seed=2, scale=1 / math.sqrt(9 * C))                 # [Cout][KH][KW][Cin]
+    xin = torch.zeros(Bc, C, Hc, Wc, requires_grad=True)
+    TF.conv2d(xin, qb(w).permute(0, 3, 1, 2), None, 1, 1).backward(qb(dy).permute(0, 3, 1, 2))
+    ref = xin.grad.permute(0, 2, 3, 1)
+    r = rnd(Bc, Hc, Wc, C, seed=3) if mode != "plain" else None
+    mref = rnd(Bc, Hc, Wc, C, seed=4) if mode == "res+relu" else None
+    if r is not None:
+        ref = ref + qb(r)
+    if mref is not None:
+        ref = ref * (qb(mref) > 0)
+    wt = qb(w).permute(3, 1, 2, 0).contiguous()                              # [Cin][KH][KW][Cout]
+    outs = {}
+    for on in (1, 0):
+        knob("conv_c64", on)
+        dx = torch.full((Bc, Hc, Wc, C), float("nan"), device=rt.device, dtype=rt.tdtype)
+        rt.call("msc_conv2d_dgrad", dev(dy, rt), dev(wt, rt), dev(r, rt) if r is not None else None, dev(mref, rt) if mref is not None else None, dx,
+                Bc, Hc, Wc, C, C, 3, 3, 1, 1, None, 0, rt.dt)
+        info = last_gemm()
+        assert (info[0] == 5) == bool(on), info
+        check(f"dx c64={on}", dx, ref, 1.2e-2)
+        outs[on] = dx
+    check("c64 vs implicit GEMM", outs[1], outs[0].float(), 1.2e-2)
+
+
+def test_conv_c64_at_benchmark_shape(rt, knob):
+    """layer 1 at 64 frames (200704 pixels, 896 tiles over the persistent workgroups): against the implicit-GEMM kernel and an fp32 reference
+    on a slice of the batch"""
+    Bc, Hc, Wc, C = 64, 56, 56, 64
+    x = rnd(Bc, Hc, Wc, C, seed=1)
+    w = rnd(C, 3, 3, C, seed=2, scale=1 / math.sqrt(9 * C))
+    xd, wd = dev(x, rt), dev(w, rt)
+    ys = {}
+    for on in (1, 0):
+        knob("conv_c64", on)
+        y = torch.full((Bc, Hc, Wc, C), float("nan"), device=rt.device, dtype=rt.tdtype)
+        rt.call("msc_conv2d_fwd", xd, wd, y, None, Bc, Hc, Wc, C, C, 3, 3, 1, 1, None, 0, rt.dt)
+        ys[on] = y
+    check("c64 vs implicit GEMM", ys[1], ys[0].float(), 1.2e-2)
+    for b in (0, 31, 63):
+        ref = TF.conv2d(qb(x[b:b + 1]).permute(0, 3, 1, 2), qb(w).permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+        check(f"image {b}", ys[1][b:b + 1], ref, 1.2e-2)
