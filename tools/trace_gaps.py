@@ -12,7 +12,7 @@ spans = [(int(rows[idx[i + 1]]['End_Timestamp']) - int(rows[idx[i] + 1]['Start_T
 _, best = min(spans)
 step = rows[idx[best] + 1: idx[best + 1] + 1]
 S = lambda r: int(r['Start_Timestamp']); E = lambda r: int(r['End_Timestamp'])
-name = lambda r: re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('unsigned short', 'bf16')[:60]
+name = lambda r: re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')).replace('void ', '').replace('unsigned short', 'bf16')[:60]
 t0, t1 = S(step[0]), max(E(r) for r in step)
 streams = sorted({r['Stream_Id'] for r in step}, key=lambda s: -sum(E(r) - S(r) for r in step if r['Stream_Id'] == s))
 main = streams[0]

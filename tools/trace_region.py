@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 pat, nb, na = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 S = lambda r: int(r['Start_Timestamp']); E = lambda r: int(r['End_Timestamp'])
-name = lambda r: re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('unsigned short', 'bf16')[:70]
+name = lambda r: re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')).replace('void ', '').replace('unsigned short', 'bf16')[:70]
 hits = [i for i, r in enumerate(rows) if pat in r['Kernel_Name']]
 k = hits[len(hits) // 2]
 t0 = S(rows[k])

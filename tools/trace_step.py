@@ -28,7 +28,7 @@ for sid in streams:
     for r in step:
         if r['Stream_Id'] != sid:
             continue
-        n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('unsigned short', 'bf16')
+        n = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')).replace('void ', '').replace('unsigned short', 'bf16')
         d[n][0] += 1; d[n][1] += dur(r)
     print(f"--- stream {sid}: {sum(v[1] for v in d.values()) / 1e3:.3f} ms")
     for k, v in sorted(d.items(), key=lambda x: -x[1][1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 25]:

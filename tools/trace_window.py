@@ -10,7 +10,7 @@ spans = [(int(rows[idx[i + 1]]['End_Timestamp']) - int(rows[idx[i] + 1]['Start_T
 _, best = min(spans)
 step = rows[idx[best] + 1:idx[best + 1] + 1]
 t0 = int(step[0]['Start_Timestamp'])
-short = lambda n: re.sub(r'\(.*', '', n).replace('void ', '').replace('unsigned short', 'bf16')[:58]
+short = lambda n: re.sub(r'\(.*', '', n.replace('(anonymous namespace)::', '')).replace('void ', '').replace('unsigned short', 'bf16')[:58]
 hits = [r for r in step if sys.argv[2] in r['Kernel_Name']]
 for h in hits[:int(sys.argv[3]) if len(sys.argv) > 3 else 3]:
     s, e = int(h['Start_Timestamp']), int(h['End_Timestamp'])
