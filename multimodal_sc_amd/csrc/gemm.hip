@@ -123,19 +123,32 @@ struct KStep { int kbase, kh, kw, co0; };
 // Strided dgrad orders its rows (input pixels) parity-class-major: class (h%S, w%S) first, then (b, h/S, w/S).  All
 // rows of a class see the same subset of filter taps ((h+P-kh) % S == 0), so a tile inside one class iterates only
 // those taps instead of multiplying 3/4 zeros (stride 2).  p.cls == 0: plain (b,h,w) order.
+// Row / pixel indices are decoded with runtime divisors (map width 56, 28, 14, 7 ...): a 32-bit integer division is a ~40-instruction
+// sequence, a row decode three of them, and every thread decodes several rows in the prologue and again in the epilogue of a tile — the
+// strided dgrad's prologue was 9 k cycles against 3.7 k for the forward (clock stamps, round 4).  fdiv: floor(x / d) through the float
+// reciprocal the host put next to d, exact for 0 <= x < 2^24 (x is exact in fp32, the estimate is off by at most one, one correction step
+// each way); p.fastdiv = 0 (some row count >= 2^24): the integer division.
+__device__ __forceinline__ int fdiv(const GemmParams& p, int x, int d, float rd) {
+  if (!p.fastdiv) return x / d;
+  int q = (int)((float)x * rd);
+  const int r = x - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
 __device__ __forceinline__ void dgrad_row_to_pixel(const GemmParams& p, int row, int& b, int& h, int& w) {
   if (p.cls) {
-    const int cid = row / p.cMc, idx = row - cid * p.cMc;
-    const int w2 = idx % p.cW2, t = idx / p.cW2;
-    const int h2 = t % p.cH2;
-    b = t / p.cH2;
-    h = h2 * p.cS + cid / p.cS;
-    w = w2 * p.cS + cid % p.cS;
+    const int cid = fdiv(p, row, p.cMc, p.rMc), idx = row - cid * p.cMc;
+    const int t = fdiv(p, idx, p.cW2, p.rW2), w2 = idx - t * p.cW2;
+    b = fdiv(p, t, p.cH2, p.rH2);
+    const int h2 = t - b * p.cH2;
+    const int ch = cid >> p.cLogS, cw = cid - (ch << p.cLogS);
+    h = h2 * p.cS + ch;
+    w = w2 * p.cS + cw;
   } else {
-    w = row % p.cW;
-    const int t = row / p.cW;
-    h = t % p.cH;
-    b = t / p.cH;
+    const int t = fdiv(p, row, p.cW, p.rW);
+    w = row - t * p.cW;
+    b = fdiv(p, t, p.cH, p.rH);
+    h = t - b * p.cH;
   }
 }
 
@@ -212,8 +225,8 @@ template <typename T, int MODE, int ROWS, int NTHR, int KB> struct OperandLoader
         const int row = row0 + r;
         const bool inside = row < rows_total;
         const int rr = inside ? row : 0;
-        const int wo = rr % p.cWo, t = rr / p.cWo;
-        const int ho = t % p.cHo, bb = t / p.cHo;
+        const int t = fdiv(p, rr, p.cWo, p.rWo), wo = rr - t * p.cWo;
+        const int bb = fdiv(p, t, p.cHo, p.rHo), ho = t - bb * p.cHo;
         a0[i] = ho * p.cS - p.cP;
         a1[i] = wo * p.cS - p.cP;
         boff[i] = inside ? (uint32_t)bb * (uint32_t)(p.cH * p.cW * p.cC) : DMA_OOB;
@@ -244,10 +257,10 @@ template <typename T, int MODE, int ROWS, int NTHR, int KB> struct OperandLoader
         a4[i] = tap - a3[i] * p.cKW;
         const int pix = k0 + r;
         kk[i] = pix;
-        a1[i] = pix % p.cWo;
-        const int t = pix / p.cWo;
-        a0[i] = t % p.cHo;
-        a2[i] = t / p.cHo;
+        const int t = fdiv(p, pix, p.cWo, p.rWo);
+        a1[i] = pix - t * p.cWo;
+        a2[i] = fdiv(p, t, p.cHo, p.rHo);
+        a0[i] = t - a2[i] * p.cHo;
       }
     }
   }
@@ -483,6 +496,50 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
       sc.ks.kbase += KT;
     }
   };
+
+  // ---- strided dgrad, tiles whose parity class sees NO filter tap (1x1 / stride-2 downsample convolutions: three of the four classes): their
+  // output is the residual or zero.  As workgroups of their own they walked the whole prologue and slab epilogue (~15 k cycles by the clock
+  // stamps) to store 16 KB; leaving early instead (first version of this path) did not help either: the launch is then bound by the
+  // DISPATCH of 1568 workgroups (entry stamps spread over 18 us), with the 392 real tiles dealt in among them.  Now (p.cls_fill, set by the
+  // launcher for 1x1 kernels) only the tap-carrying class is launched and each of its workgroups also copies / clears the rows of the
+  // sibling classes of its pixel region after its own epilogue.  fill_rows: rows [fm0, fm0 + BM) x columns [fn0, fn0 + BN) <- residual or 0.
+  auto fill_rows = [&](int fm0, int fn0) {
+    constexpr int FV = 16 / sizeof(T), FCP = BN / FV;
+    T* Cb = reinterpret_cast<T*>(p.C);
+    const T* Rf = reinterpret_cast<const T*>(p.res);
+    const bool vec_ok = (p.ldc % FV) == 0;
+    for (int id = tid; id < BM * FCP; id += NTHR) {
+      const int row = id / FCP, cc = id - row * FCP;
+      const int m = fm0 + row, n = fn0 + cc * FV;
+      if (m >= p.M || n >= p.N) continue;
+      int bb, hh, ww;
+      dgrad_row_to_pixel(p, m, bb, hh, ww);
+      const long o = (((long)bb * p.cH + hh) * p.cW + ww) * p.ldc + n;
+      if (vec_ok && n + FV <= p.N) {
+        vecf<T> v;
+        if (Rf) v.load(Rf + o);
+        else
+#pragma unroll
+          for (int e = 0; e < FV; ++e) v.v[e] = 0.f;
+        v.store(Cb + o);
+      } else {
+        for (int e = 0; e < FV && n + e < p.N; ++e) msc_traits<T>::st(Cb + o + e, Rf ? msc_traits<T>::ld(Rf + o + e) : 0.f);
+      }
+    }
+  };
+  if constexpr (AMODE == OPM_CONV_DGRAD && !PERSIST && EPX == 0) {
+    // (launches that cannot take cls_fill — a tile height that does not divide the class — still skip the staging for a no-tap tile)
+    if (p.cls && !p.cls_fill && p.nsplit == 1 && !p.out_f32 && !p.bias && !p.stats && p.act == MSC_ACT_NONE && !p.C2) {
+      Geo g0;
+      decode(0, g0);
+      Sched s0;
+      sched_setup(g0.m0, 0, s0);
+      if (s0.nk == 0) {
+        fill_rows(g0.m0, g0.n0);
+        return;
+      }
+    }
+  }
 
   // ---- issue side: (tile iw, step ik of isc.nk) and the loaders positioned there
   LA la;
@@ -1000,6 +1057,12 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
       reduce_cols(csum, p.colsum + (long)tile_m * p.N);
     }
   }
+    if constexpr (AMODE == OPM_CONV_DGRAD && !PERSIST && EPX == 0) {
+      if (p.cls_fill) {      // the sibling classes of this tile's pixel region (no taps there): residual or zero
+        const int ncls = p.cS * p.cS;
+        for (int c = 1; c < ncls; ++c) fill_rows(m0 + c * p.cMc, n0);
+      }
+    }
     if constexpr (PERSIST) EP_SYNC();   // the slab is free again before the next tile's epilogue touches it
 #ifdef GEMM_STAMP
     EP_STAMP(se5);
@@ -1217,6 +1280,15 @@ static int launch_gemm(const GemmParams& p, int batch, hipStream_t st) {
   }
   if (bm > 128 || bn > 128) return MSC_ERR_UNSUPPORTED;
   dim3 grid((unsigned)(cdiv(p.M, bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
+  if constexpr (AMODE == OPM_CONV_DGRAD && EPX == 0) {
+    // 1x1 strided kernels (pad 0): only parity class 0 has a tap; launch its tiles alone, they fill the sibling classes' rows (kernel: fill_rows)
+    if (p.cls && p.cKH == 1 && p.cKW == 1 && p.cP == 0 && p.nsplit == 1 && !p.out_f32 && !p.bias && !p.stats && p.act == MSC_ACT_NONE && !p.C2 &&
+        p.cMc % bm == 0 && mscplan::g_knobs.dgrad_cls_fill) {
+      q.cls_fill = 1;
+      q.cls_interleave = 0;
+      grid = dim3((unsigned)((p.cMc / bm) * cdiv(p.N, bn)), 1, (unsigned)zs);
+    }
+  }
   // K bytes per step / ring depth / waves of the multi-workgroup kernels (measured per operand mode, tools/gemm_sweep.py):
   // gathered weight gradients (conv wgrad) run best on 64-byte steps x 3 stages x 4 waves (three workgroups per CU);
   // everything else on 128-byte steps x 2 stages, the 128x128 tile with 8 waves
@@ -1299,6 +1371,8 @@ static int set_conv_geom(GemmParams& p, int B, int H, int W, int C, int Ho, int 
   p.cB = B; p.cH = H; p.cW = W; p.cC = C; p.cHo = Ho; p.cWo = Wo; p.cKH = KH; p.cKW = KW; p.cS = s; p.cP = pad;
   p.cLogC = ilog2_exact(C);
   p.cLogS = ilog2_exact(s);
+  p.rW = 1.f / (float)W; p.rH = 1.f / (float)H; p.rWo = 1.f / (float)Wo; p.rHo = 1.f / (float)Ho;
+  p.fastdiv = ((long)B * H * W < (1L << 24) && (long)B * Ho * Wo < (1L << 24)) ? 1 : 0;     // every decoded index is a row / pixel index below these
   return (p.cLogC >= 0 && p.cLogS >= 0) ? MSC_OK : MSC_ERR_BAD_ARG;
 }
 
@@ -1422,6 +1496,7 @@ static int conv2d_dgrad_impl(const void* dy, const void* wt, const void* res, co
     p.cH2 = H / stride;
     p.cW2 = W / stride;
     p.cMc = B * p.cH2 * p.cW2;
+    p.rMc = 1.f / (float)p.cMc; p.rW2 = 1.f / (float)p.cW2; p.rH2 = 1.f / (float)p.cH2;
     // a tile that straddles two parity classes iterates all taps instead of the 1/S^2 its class sees: keep the row tiles
     // inside the classes when a 64-row tile does that and a 128-row one does not (layer 4 at 64 frames: 3136 rows per
     // class — measured 67 -> 32 us)

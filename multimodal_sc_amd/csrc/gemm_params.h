@@ -16,7 +16,10 @@ struct GemmParams {
   // geometry of the gathered NHWC tensor (conv modes)
   int cB, cH, cW, cC, cHo, cWo, cKH, cKW, cS, cP, cLogC, cLogS;
   int cls, cMc, cH2, cW2;   // strided dgrad: parity-class-major row order (rows per class, H/S, W/S)
+  float rW, rH, rWo, rHo, rMc, rW2, rH2;   // reciprocals of the decode divisors (gemm.hip fdiv)
+  int fastdiv;              // host: every row / pixel index of the launch is below 2^24 -> fdiv may use them
   int cls_interleave;       // set by the launcher when cMc is a multiple of the tile height it picked
+  int cls_fill;             // set by the launcher for 1x1 strided dgrads: only class 0's tiles are launched, each fills its siblings' rows
   unsigned long long* stamps;   // GEMM_STAMP diagnostic build only (else null and unused)
   int bm_cap;                   // host only: largest tile height the launch may use (0 = no cap)
   float* rowsum;                // weight-gradient launches (both operands mn-major): fp32 [nsplit][M] sums over the reduction of the
