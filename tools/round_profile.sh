@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: the profiles committed under profiles/r4_* (kernel trace + stats of the normal multi-stream bench and of the single-stream
-# instrumented passes, PMC passes in their own runs, step composition).  The -m gpu suite / smoke / bench line: tools/r4_final_a.sh;
-# what-if table, host overhead, host-inputs leg: tools/r4_final_c.sh
+# instrumented passes, PMC passes in their own runs, step composition).  The -m gpu suite / smoke / bench line: tools/r4_runs/r4_final_a.sh;
+# what-if table, host overhead, host-inputs leg: tools/r4_runs/r4_final_c.sh
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=gpurun_out/r4r; rm -rf $R; mkdir -p $R
