@@ -291,7 +291,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         if constexpr (ACT == MSC_ACT_GELU_DSAVE) {
           float d[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) gelu_both(v[e], v[e], d[e]);
+          for (int e = 0; e < 4; ++e) {          // two elements per call: packed fp32 arithmetic (msc_common.h gelu_both2)
+            msc_f32x2 yy, dd;
+            gelu_both2((msc_f32x2){v[2 * e], v[2 * e + 1]}, yy, dd);
+            v[2 * e] = yy[0]; v[2 * e + 1] = yy[1];
+            d[2 * e] = dd[0]; d[2 * e + 1] = dd[1];
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) w2[e] = pp_pack2(d[2 * e], d[2 * e + 1]);
         } else {

@@ -146,6 +146,28 @@ __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
   dy = fmaf(x * 0.3989422804014327f, e, 0.5f * (1.f + erfv));
 }
 
+// gelu_both on TWO elements: the polynomial / product part on the packed fp32 instructions of gfx950 (v_pk_fma_f32, v_pk_mul_f32: two lanes'
+// worth per issue slot), the two transcendentals per element as before — 23 instructions per pair against 27 per element.  The epilogue of
+// the widest GEMM of the transformer (fc1: GELU + derivative over 19584 x 2048 outputs per layer) is bound by exactly this arithmetic.
+typedef __attribute__((ext_vector_type(2))) float msc_f32x2;
+__device__ __forceinline__ void gelu_both2(msc_f32x2 x, msc_f32x2& y, msc_f32x2& dy) {
+  const msc_f32x2 one = {1.f, 1.f}, half = {0.5f, 0.5f};
+  const msc_f32x2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+  const msc_f32x2 den = __builtin_elementwise_fma(ax, (msc_f32x2){0.3275911f, 0.3275911f}, one);
+  const msc_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  msc_f32x2 q = __builtin_elementwise_fma((msc_f32x2){1.061405429f, 1.061405429f}, t, (msc_f32x2){-1.453152027f, -1.453152027f});
+  q = __builtin_elementwise_fma(q, t, (msc_f32x2){1.421413741f, 1.421413741f});
+  q = __builtin_elementwise_fma(q, t, (msc_f32x2){-0.284496736f, -0.284496736f});
+  q = __builtin_elementwise_fma(q, t, (msc_f32x2){0.254829592f, 0.254829592f});
+  const msc_f32x2 a2 = ax * ax;
+  const msc_f32x2 e = {__expf(-a2[0]), __expf(-a2[1])};
+  const msc_f32x2 erfa = one - q * t * e;
+  const msc_f32x2 erfv = {copysignf(erfa[0], x[0]), copysignf(erfa[1], x[1])};
+  const msc_f32x2 ph = __builtin_elementwise_fma(erfv, half, half);     // Phi(x)
+  y = x * ph;
+  dy = __builtin_elementwise_fma(x * 0.3989422804014327f, e, ph);
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
     case MSC_ACT_RELU: return x > 0.f ? x : 0.f;
