@@ -57,6 +57,7 @@ _FUSED_BIAS = os.environ.get("MSC_FUSED_BIAS", "1") != "0"    # A/B knob: 0 = bi
 # the round-2 review (item 3a), correct — and +0.03 ms in the step (profiles/r3_bn_stat_fuse_ab.txt): the heavier epilogue costs the dgrad
 # more than the 8 reduction launches it removes returned
 _BN_STAT_FUSE = os.environ.get("MSC_BN_STAT_FUSE", "0") != "0"
+_STEM_HOOK_AT = os.environ.get("MSC_STEM_HOOK_AT", "wgrad")       # experiment knob: "start" = before the stem's BatchNorm / pooling backward
 _GELU_DSAVE = os.environ.get("MSC_GELU_DSAVE", "1") != "0"
 _GELU_FWD, _GELU_BWD = (L.ACT_GELU_DSAVE, L.ACT_MUL_REF) if _GELU_DSAVE else (L.ACT_GELU, L.ACT_GELU)
 
@@ -172,6 +173,8 @@ class StemFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y_raw, stats, idx, xsel = ctx.saved_tensors
         rt, conv, gamma, beta, stride, pad, pK, pS, pP, s2d = ctx.cfg
+        if rt.on_stem_backward is not None and _STEM_HOOK_AT == "start":
+            rt.on_stem_backward()
         B, H, W, Cin = x.shape
         Cout, KH, KW, _ = conv.shape
         _, Ho, Wo, _ = y_raw.shape
@@ -179,6 +182,11 @@ class StemFn(torch.autograd.Function):
         ws = rt.workspace("bn_bwd", L.query("msc_bn_bwd_workspace_bytes", Cout))
         rt.call("msc_bn_relu_pool_bwd", dy.contiguous(), idx, xsel, y_raw, stats[0], stats[1], gamma.p, stats[2], stats[3], d_raw, gamma.g, beta.g,
                 ws, B, Ho, Wo, Cout, pK, pS, pP, rt.accumulate, rt.dt)
+        # last node of the backward: every other encoder parameter's gradient has its producer enqueued.  The Trainer puts their optimizer update
+        # onto the side stream here — behind the BatchNorm / pooling backward above (two memory-bound passes that would share HBM with it), beside
+        # the stem's weight gradient below
+        if rt.on_stem_backward is not None and _STEM_HOOK_AT != "start":
+            rt.on_stem_backward()
         if s2d:
             # (the stem is the last node of the backward: its weight gradient runs on the launching stream, see conv_bn_bwd)
             wsb = L.query("msc_wgrad_workspace_bytes", Cout, 256, B * Ho * Wo)

@@ -92,6 +92,7 @@ class Runtime:
         self.taps = None             # dict -> conv_bn_fwd records the post-ReLU output of every conv+BN+ReLU by weight name (tests)
         self.fused_attention = True  # bf16: flash-style kernel; False forces the batched-GEMM + softmax path (tests)
         self.on_upper_grads_ready = None   # callback fired in backward once G[fusion.pos_embed:] is final (DP overlap)
+        self.on_stem_backward = None       # callback fired when the LAST node of the backward (the ImageEncoder stem) starts enqueueing (Trainer)
         self.side = None                   # second HIP stream for the weight-gradient GEMMs (call_side / join_side)
         self._side_dirty = False
         self._side_keep = []
@@ -271,6 +272,7 @@ class ParamStore:
         self.stem = self.refs.get("image_encoder.conv1.weight")
         self.stem_w = torch.zeros(self.stem.shape[0] * 256, dtype=rt.tdtype, device=dev) if self.stem is not None else None
         self.step_count = 0
+        self._early = None         # (lo, hi, hyper-parameter tuple) of this step's adam_early() call
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # device-side step counter (hipGraph replay)
         self._ptable = None
         self._ptable_split = None
@@ -278,9 +280,10 @@ class ParamStore:
     def __getitem__(self, name) -> ParamRef:
         return self.refs[name]
 
-    def _tables(self, split):
-        """descriptor tables of the weight transposes (one launch instead of one per weight): all / below split / above split"""
-        if self._ptable is None or self._ptable_split != split:
+    def _tables(self, split, mid=None):
+        """descriptor tables of the weight transposes (one launch instead of one per weight): all / below split / above split
+        (+ with mid: "rest" = below mid, "mid" = [mid, split))"""
+        if self._ptable is None or self._ptable_split != (split, mid):
             def build(lo, hi):
                 rows, blk = [], 0
                 for r in self.refs.values():
@@ -299,7 +302,9 @@ class ParamStore:
             self._ptable = {"all": build(0, self.total)}
             if split:
                 self._ptable["lo"], self._ptable["hi"] = build(0, split), build(split, self.total)
-            self._ptable_split = split
+                if mid:
+                    self._ptable["rest"], self._ptable["mid"] = build(0, mid), build(mid, split)
+            self._ptable_split = (split, mid)
         return self._ptable
 
     def refresh_compute_copies(self, cast: bool = True):
@@ -307,7 +312,7 @@ class ParamStore:
         rt = self.rt
         if cast and rt.dt != L.MSC_F32:
             rt.call("msc_cast", self.P, self.C, self.total, rt.dt)
-        t, blk = self._tables(self._ptable_split)["all"]
+        t, blk = self._tables(*(self._ptable_split or (None, None)))["all"]
         rt.call("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
         self._refresh_stem()
 
@@ -315,30 +320,52 @@ class ParamStore:
         if self.stem is not None:
             self.rt.call("msc_stem_weight_s2d", self.stem.p, self.stem_w, self.stem.shape[0], self.rt.dt)
 
+    def _adam_hp(self, lr, betas, eps, weight_decay, grad_scale):
+        rt = self.rt
+        self.step_count += 1
+        if rt.host_counters:
+            return (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.step_count, None, float(grad_scale), rt.dt)
+        rt.call("msc_counter_add", self.step_dev, 1)      # the kernels read the step from device memory, so the same launches replay correctly
+        return (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, self.step_dev, float(grad_scale), rt.dt)
+
+    def adam_early(self, lo, hi, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        """Update of the slice [lo, hi) of the flat buffers on the side stream, behind the weight-gradient GEMMs that produced its gradients,
+        while the launching stream still has backward work of OTHER parameters to do.  The caller has ordered the side stream behind every
+        stream that wrote gradients of the slice or still reads its weights.  adam_step() of the same step then updates [0, lo) and
+        [hi, total) only (hi must be its overlap_from).  Returns False (nothing done) where adam_step would not split either."""
+        rt = self.rt
+        if not (rt.wgrad_on_side and rt.profile is None and not torch.cuda.is_current_stream_capturing()):
+            return False
+        hp = self._adam_hp(lr, betas, eps, weight_decay, grad_scale)
+        shadow = None if rt.dt == L.MSC_F32 else self.C[lo:hi]
+        rt.call_side("msc_adam_step", self.P[lo:hi], self.G[lo:hi], self.M[lo:hi], self.V[lo:hi], shadow, hi - lo, *hp)
+        t, blk = self._tables(hi, lo)["mid"]
+        if t is not None:
+            rt.call_side("msc_permute3_cast_batched", self.P, self.TR, t, t.shape[0], blk, rt.dt)
+        self._early = (lo, hi, hp)
+        return True
+
     def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, overlap_from=None):
         """Fused Adam (+ bf16 shadow) over the flat buffers, then the transposed compute copies.
         overlap_from = element offset: parameters from there on (fusion transformer, codec, heads) are updated on the side
         stream, where the update overlaps the camera/BEV trunks of the NEXT forward; MultimodalSC.forward joins the side
         stream before the fusion reads them.  Not used while a hipGraph is being captured or in the instrumented pass."""
         rt = self.rt
-        self.step_count += 1
-        if rt.host_counters:
-            hp = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.step_count, None,
-                  float(grad_scale), rt.dt)
-        else:
-            rt.call("msc_counter_add", self.step_dev, 1)      # the kernels read the step from device memory, so the
-            hp = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, self.step_dev,
-                  float(grad_scale), rt.dt)                     # same launches replay correctly from a hipGraph
+        early, self._early = self._early, None
+        hp = early[2] if early else self._adam_hp(lr, betas, eps, weight_decay, grad_scale)
         split = overlap_from if (overlap_from and rt.wgrad_on_side and rt.profile is None
                                  and not torch.cuda.is_current_stream_capturing()) else None
+        if early:
+            assert split == early[1], "adam_early() updated [lo, split): the step's adam_step must split at the same offset"
         if not split:
             rt.call("msc_adam_step", self.P, self.G, self.M, self.V, None if rt.dt == L.MSC_F32 else self.C, self.total, *hp)
             self.refresh_compute_copies(cast=False)
             return
-        tabs = self._tables(split)
+        lo_end = early[0] if early else split          # [lo_end, split) was updated by adam_early()
+        tabs = self._tables(split, early[0] if early else (self._ptable_split or (None, None))[1])
         shadow = lambda a, b: None if rt.dt == L.MSC_F32 else self.C[a:b]
-        rt.call("msc_adam_step", self.P[:split], self.G[:split], self.M[:split], self.V[:split], shadow(0, split), split, *hp)
-        t, blk = tabs["lo"]
+        rt.call("msc_adam_step", self.P[:lo_end], self.G[:lo_end], self.M[:lo_end], self.V[:lo_end], shadow(0, lo_end), lo_end, *hp)
+        t, blk = tabs["rest"] if early else tabs["lo"]
         if t is not None:
             # the transposed copies feed the dgrads only: off the step boundary's critical path, onto the side stream (which waits for the
             # update above; the next forward joins the side stream before the fusion, long before the first dgrad).  MSC_TR_LO_SIDE=0: main

@@ -140,6 +140,8 @@ class Trainer:
             # pays for the boundary (one GPU: 8.12 -> 8.25 ms); two-piece, non-overlapped and hipGraph DP keep the uncut trunk
             model._img_cut = 3
         self.adam_overlap = os.environ.get("MSC_ADAM_OVERLAP", "1") != "0" and not self.use_graph
+        # single-rank step: the encoder half of the update (minus the stem's own parameters) on the side stream beside the stem's backward
+        self.adam_early = os.environ.get("MSC_ADAM_EARLY", "1") != "0" and self.adam_overlap and not self.dp
         self.use_replay = os.environ.get("MSC_REPLAY", "1") != "0" and not self.use_graph
         self.replay_warmup = int(os.environ.get("MSC_REPLAY_WARMUP", "2"))   # eager (arena) steps before the recorded one
         if self.use_replay:
@@ -174,12 +176,28 @@ class Trainer:
             m.rt.join_side()          # upper weight gradients (side stream) are final behind this point
         return out, terms
 
-    def forward_backward(self, batch):
-        """forward + complete backward (no collective) — used by the eager path, bench.py's instrumented pass, tests"""
+    def forward_backward(self, batch, adam_early=False):
+        """forward + complete backward (no collective) — used by the eager path, bench.py's instrumented pass, tests.
+        adam_early (single-rank step; the caller runs _adam() next): when the last node of the backward — the ImageEncoder stem — starts
+        enqueueing, every other encoder gradient has its producer enqueued; the update of those parameters goes onto the side stream right
+        there (behind their weight gradients) and runs beside the stem's backward instead of on the main stream after it."""
         m = self.model
         out = m(batch["image"], batch.get("points"), batch.get("state"), batch["snr_db"], batch.get("noise"), batch.get("fading"))
-        terms = m.loss_and_grads(out, batch["image"], batch.get("ppo") if self.use_ppo else None)
+        m.rt.on_stem_backward = self._adam_encoders_early if adam_early else None
+        try:
+            terms = m.loss_and_grads(out, batch["image"], batch.get("ppo") if self.use_ppo else None)
+        finally:
+            m.rt.on_stem_backward = None
         return out, terms
+
+    def _adam_encoders_early(self):
+        m, rt = self.model, self.model.rt
+        first = m.params.refs.get("image_encoder.layer1.0.conv1.weight")
+        if rt.side is None or first is None or first.off >= self.split:
+            return
+        if rt._branch is not None:      # the BEV branch's gradients / its data gradients' weight reads (call_side orders the side stream behind main)
+            rt.stream_wait(rt._side_raw, rt._branch.cuda_stream)
+        m.params.adam_early(first.off, self.split, lr=self.lr, grad_scale=1.0 / self.world)
 
     def _allreduce_mid(self):
         """all-reduce of G[mid:split] (top of the camera trunk, BEV branch, state encoder: ~41 of the 52 MB of encoder
@@ -213,7 +231,7 @@ class Trainer:
     def _eager_step(self, batch):
         m, G = self.model, self.model.params.G
         if not self.dp:
-            _, terms = self.forward_backward(batch)
+            _, terms = self.forward_backward(batch, adam_early=self.adam_early)
         elif self.overlap:
             _, terms = self._forward_upper(batch)
             if self.exchange is None:
