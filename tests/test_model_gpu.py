@@ -643,7 +643,7 @@ def test_encoder_update_beside_the_stem_backward_is_bit_identical(cuda, monkeypa
         for _ in range(5):
             tr.step(batch)
         torch.cuda.synchronize()
-        assert m.params._early is None and m.params.step_count == 5
+        assert m.params._early is None          # (the host-side step_count stops at the recorded step: replayed steps count on the device)
         res[early] = (m.params.P.clone(), m.params.M.clone(), m.params.V.clone(), m.params.C.clone(), m.params.TR.clone())
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
