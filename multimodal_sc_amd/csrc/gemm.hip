@@ -1193,6 +1193,8 @@ int msc_pp_launch(const GemmParams& p, int ncu, hipStream_t st);
 bool msc_conv_c64_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype);      // conv_c64.hip: ResNet layer 1
 int msc_conv_c64_launch(const void* x, const void* w, void* y, const void* res, const void* relu_ref, float* part, int part_rows, int B, int H,
                         int flip, int ncu, hipStream_t st);
+bool msc_stem_wgrad_halo_ok(int B, int Hs, int Ws, int Cout, int dtype, int64_t ws_bytes);      // conv_stem.hip
+int msc_stem_wgrad_halo_launch(const void* xs, const void* dy, float* slab, int64_t slab_bytes, int B, int Hs, int ncu, hipStream_t st);
 bool msc_skinny_ok(const GemmParams& p);                    // gemm_skinny.hip: dense bf16 linears of at most 64 rows
 int msc_skinny_launch(const GemmParams& p, hipStream_t st);
 // the most recent contraction launch of this process, for tests that assert which kernel variant a shape took (msc_debug_last_gemm):
@@ -1331,6 +1333,7 @@ extern "C" int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out,
 
 // db (optional, linear layers): bias gradient [M] = row sums of the A operand, produced by the same launch (p.rowsum) and
 // reduced over the K slices by extra blocks of the reduce launch
+static int launch_splitk_reduce(const float* ws, float* dw, long n4, int ns, int accumulate, const float* ws_rows, float* db, long n4b, hipStream_t st);
 static int finish_wgrad(GemmParams& p, float* dw, float* db, float* ws, int64_t ws_bytes, long reduce_len, int accumulate,
                         int dtype, hipStream_t st, int (*launch)(const GemmParams&, int, int, hipStream_t), int kstep_bytes) {
   const mscplan::WgradSplit w = mscplan::wgrad_split(p.M, p.N, reduce_len, kstep_bytes / esize(dtype), kstep_bytes == 64 /* gathered conv wgrad */);
@@ -1352,9 +1355,12 @@ static int finish_wgrad(GemmParams& p, float* dw, float* db, float* ws, int64_t 
   }
   int rc = launch(p, 1, dtype, st);
   if (rc != MSC_OK) return rc;
-  const long n4 = (long)p.M * p.N / 4;
+  return launch_splitk_reduce(ws, dw, (long)p.M * p.N / 4, ns, accumulate, ws_rows, db, db ? p.M / 4 : 0, st);
+}
+
+// fixed-order sum of ns fp32 slabs of n4 float4 each into dw (+ the [ns][n4b] row-sum slabs into db)
+static int launch_splitk_reduce(const float* ws, float* dw, long n4, int ns, int accumulate, const float* ws_rows, float* db, long n4b, hipStream_t st) {
   const unsigned blocks = (unsigned)cdiv(n4, 64);
-  const long n4b = db ? p.M / 4 : 0;
   const unsigned grid = blocks + (unsigned)cdiv(n4b, 64);
   // slab groups per block: as many as keep >= ~4 waves per CU busy, at most the slab count
   int ry = 1;
@@ -1463,6 +1469,12 @@ extern "C" int msc_stem_s2d_conv_wgrad(const void* xs, const void* dy, float* dw
   MSC_CHECK_ARG(xs && dy && dw_s2d && B > 0 && Hs > 0 && Ws > 0 && Cout % vec_of(dtype) == 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   if (!fits32((long)B * Hs * Ws * 16, dtype) || !fits32((long)B * Hs * Ws * Cout, dtype)) return MSC_ERR_UNSUPPORTED;
+  if (msc_stem_wgrad_halo_ok(B, Hs, Ws, Cout, dtype, ws_bytes) && ws) {     // both operands staged once per tile, accumulators resident: conv_stem.hip
+    const int nwg = msc_stem_wgrad_halo_launch(xs, dy, ws, ws_bytes, B, Hs, num_cus(), (hipStream_t)stream);
+    if (nwg < 0) return -nwg;
+    note_gemm(6, 224, 256, 256, nwg, 0, 0, 0);
+    return launch_splitk_reduce(ws, dw_s2d, (long)Cout * 256 / 4, nwg, accumulate, nullptr, nullptr, 0, (hipStream_t)stream);
+  }
   GemmParams p = base_params();
   p.A = dy; p.B = xs;
   p.M = Cout; p.N = 256; p.K = B * Hs * Ws;

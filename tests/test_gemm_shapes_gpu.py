@@ -470,3 +470,41 @@ def test_conv_c64_at_benchmark_shape(rt, knob):
     for b in (0, 31, 63):
         ref = TF.conv2d(qb(x[b:b + 1]).permute(0, 3, 1, 2), qb(w).permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
         check(f"image {b}", ys[1][b:b + 1], ref, 1.2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ stem weight gradient: the halo-resident kernel
+@pytest.mark.parametrize("Bs,Hs", [(2, 112), (1, 2), (3, 6), (64, 112)])
+def test_stem_wgrad_halo(rt, knob, Bs, Hs):
+    """weight gradient of the space-to-depth stem (4x4 / stride 1, pad 2 before / 1 after, 16 -> 64 channels on 112-wide maps) through conv_stem.hip
+    (both operands staged once per tile, transposed LDS reads, accumulators resident across the workgroup's tiles, fixed-order reduce of the
+    workgroups' partials) against the autograd weight gradient of fp32 PyTorch from bf16-rounded inputs, against the gathered split-K GEMM,
+    and bit-identical when repeated.  Heights 2 / 6: every tile touches the zero padding above or below; 3 images x 3 tiles: odd tile count."""
+    from multimodal_sc_amd import lib as L
+    Ws, Cout = 112, 64
+    xs = rnd(Bs, Hs, Ws, 16, seed=1)
+    dy = rnd(Bs, Hs, Ws, Cout, seed=2, scale=0.1)
+    w = torch.zeros(Cout, 16, 4, 4, requires_grad=True)
+    xin = TF.pad(qb(xs).permute(0, 3, 1, 2), (2, 1, 2, 1))
+    TF.conv2d(xin, w).backward(qb(dy).permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, 256)                   # [co][kh][kw][c]
+    wsb = L.query("msc_wgrad_workspace_bytes", Cout, 256, Bs * Hs * Ws)
+    ws = torch.empty(wsb // 4, device=rt.device)
+    xd, dyd = dev(xs, rt), dev(dy, rt)
+    outs = {}
+    for on in (1, 0):
+        knob("stem_wgrad_halo", on)
+        dw = torch.full((Cout, 256), float("nan"), device=rt.device)
+        rt.call("msc_stem_s2d_conv_wgrad", xd, dyd, dw, ws, wsb, Bs, Hs, Ws, Cout, 0, rt.dt)
+        info = last_gemm()
+        assert (info[0] == 6) == bool(on), info
+        check(f"dw halo={on}", dw, ref, 2e-3)
+        outs[on] = dw
+    check("halo vs gathered GEMM", outs[1], outs[0], 2e-3)
+    knob("stem_wgrad_halo", 1)
+    dw2 = torch.full((Cout, 256), float("nan"), device=rt.device)
+    rt.call("msc_stem_s2d_conv_wgrad", xd, dyd, dw2, ws, wsb, Bs, Hs, Ws, Cout, 0, rt.dt)
+    acc = outs[1].clone()
+    rt.call("msc_stem_s2d_conv_wgrad", xd, dyd, acc, ws, wsb, Bs, Hs, Ws, Cout, 1, rt.dt)        # accumulate = 1: adds to what is there
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, outs[1])
+    check("accumulate", acc, 2 * ref, 2e-3)
