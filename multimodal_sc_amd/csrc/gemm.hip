@@ -1195,6 +1195,9 @@ int msc_conv_c64_launch(const void* x, const void* w, void* y, const void* res, 
                         int flip, int ncu, hipStream_t st);
 bool msc_stem_wgrad_halo_ok(int B, int Hs, int Ws, int Cout, int dtype, int64_t ws_bytes);      // conv_stem.hip
 int msc_stem_wgrad_halo_launch(const void* xs, const void* dy, float* slab, int64_t slab_bytes, int B, int Hs, int ncu, hipStream_t st);
+bool msc_conv_c64_wgrad_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype, int64_t ws_bytes);      // conv_c64w.hip
+int64_t msc_conv_c64_wgrad_workspace_bytes(int ncu);
+int msc_conv_c64_wgrad_launch(const void* x, const void* dy, float* slab, int64_t slab_bytes, int B, int H, int ncu, hipStream_t st);
 bool msc_skinny_ok(const GemmParams& p);                    // gemm_skinny.hip: dense bf16 linears of at most 64 rows
 int msc_skinny_launch(const GemmParams& p, hipStream_t st);
 // the most recent contraction launch of this process, for tests that assert which kernel variant a shape took (msc_debug_last_gemm):
@@ -1328,7 +1331,13 @@ static inline int esize(int dtype) { return dtype == MSC_F32 ? 4 : 2; }
 static inline bool fits32(long elems, int dtype) { return elems * esize(dtype) < 0x7ffffff0L; }
 
 extern "C" int64_t msc_wgrad_workspace_bytes(int64_t rows_out, int64_t cols_out, int64_t reduce_len) {
-  return mscplan::wgrad_workspace_bytes(rows_out, cols_out, reduce_len);
+  int64_t b = mscplan::wgrad_workspace_bytes(rows_out, cols_out, reduce_len);
+  // the layer-1 kernel of conv_c64w.hip keeps one 64 x 576 partial per workgroup, one workgroup per CU (256 on MI355X; fewer slabs = fewer workgroups)
+  if (rows_out == 64 && cols_out == 576) {
+    const int64_t w = msc_conv_c64_wgrad_workspace_bytes(256);
+    if (w > b) b = w;
+  }
+  return b;
 }
 
 // db (optional, linear layers): bias gradient [M] = row sums of the A operand, produced by the same launch (p.rowsum) and
@@ -1544,6 +1553,12 @@ extern "C" int msc_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   MSC_CHECK_ARG(Ho > 0 && Wo > 0);
   if (!fits32((long)B * H * W * Cin, dtype) || !fits32((long)B * Ho * Wo * Cout, dtype)) return MSC_ERR_UNSUPPORTED;
+  if (ws && msc_conv_c64_wgrad_ok(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype, ws_bytes)) {     // ResNet layer 1: conv_c64w.hip
+    const int nwg = msc_conv_c64_wgrad_launch(x, dy, ws, ws_bytes, B, H, num_cus(), (hipStream_t)stream);
+    if (nwg < 0) return -nwg;
+    note_gemm(7, 224, 576, 256, nwg, 0, 0, 0);
+    return launch_splitk_reduce(ws, dw, (long)Cout * 576 / 4, nwg, accumulate, nullptr, nullptr, 0, (hipStream_t)stream);
+  }
   GemmParams p = base_params();
   p.A = dy; p.B = x;
   p.M = Cout; p.N = KH * KW * Cin; p.K = B * Ho * Wo;

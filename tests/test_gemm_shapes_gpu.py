@@ -229,7 +229,10 @@ def test_conv_at_benchmark_shape(rt, name, H, Cin, Cout, K, s, p):
     wsb3 = torch.empty(wsw // 4, device=rt.device)
     rt.call("msc_conv2d_wgrad", xd, dev(dy, rt), dw, wsb3, wsw, B, H, H, Cin, Cout, K, K, s, p, 0, rt.dt)
     wg = last_gemm()
-    assert wg[0] == 1 and wg[3] == 256 and wg[4] >= 1, wg                     # gathered weight gradient: 4 waves, 64-byte K steps
+    if layer1:
+        assert wg[0] == 7 and wg[1:4] == (224, 576, 256), wg                  # conv_c64w.hip: both operands staged once per 224-pixel tile
+    else:
+        assert wg[0] == 1 and wg[3] == 256 and wg[4] >= 1, wg                 # gathered weight gradient: 4 waves, 64-byte K steps
     check("dw", dw, wq.grad.permute(0, 1, 2, 3), 2e-3 * 4)
 
 
@@ -505,6 +508,42 @@ def test_stem_wgrad_halo(rt, knob, Bs, Hs):
     rt.call("msc_stem_s2d_conv_wgrad", xd, dyd, dw2, ws, wsb, Bs, Hs, Ws, Cout, 0, rt.dt)
     acc = outs[1].clone()
     rt.call("msc_stem_s2d_conv_wgrad", xd, dyd, acc, ws, wsb, Bs, Hs, Ws, Cout, 1, rt.dt)        # accumulate = 1: adds to what is there
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, outs[1])
+    check("accumulate", acc, 2 * ref, 2e-3)
+
+
+@pytest.mark.parametrize("Bc,Hc", [(2, 56), (1, 4), (3, 12), (64, 56)])
+def test_conv_c64_wgrad(rt, knob, Bc, Hc):
+    """weight gradient of the layer-1 convolutions through conv_c64w.hip (dy tile and x halo staged once, transposed LDS reads, 36 accumulators per
+    wave resident across the workgroup's tiles, fixed-order reduce of the partials) against the autograd weight gradient of fp32 PyTorch from
+    bf16-rounded inputs, against the gathered split-K GEMM, bit-identical when repeated, accumulate mode"""
+    from multimodal_sc_amd import lib as L
+    Wc, C = 56, 64
+    x = rnd(Bc, Hc, Wc, C, seed=1)
+    dy = rnd(Bc, Hc, Wc, C, seed=2, scale=0.1)
+    w = torch.zeros(C, C, 3, 3, requires_grad=True)
+    TF.conv2d(qb(x).permute(0, 3, 1, 2), w, None, 1, 1).backward(qb(dy).permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).contiguous()                           # [Cout][KH][KW][Cin]
+    wsb = L.query("msc_wgrad_workspace_bytes", C, 9 * C, Bc * Hc * Wc)
+    assert wsb >= 256 * 64 * 576 * 4
+    ws = torch.empty(wsb // 4, device=rt.device)
+    xd, dyd = dev(x, rt), dev(dy, rt)
+    outs = {}
+    for on in (1, 0):
+        knob("conv_c64", on)
+        dw = torch.full((C, 3, 3, C), float("nan"), device=rt.device)
+        rt.call("msc_conv2d_wgrad", xd, dyd, dw, ws, wsb, Bc, Hc, Wc, C, C, 3, 3, 1, 1, 0, rt.dt)
+        info = last_gemm()
+        assert (info[0] == 7) == bool(on), info
+        check(f"dw c64={on}", dw, ref, 2e-3)
+        outs[on] = dw
+    check("c64 vs gathered GEMM", outs[1], outs[0], 2e-3)
+    knob("conv_c64", 1)
+    dw2 = torch.full((C, 3, 3, C), float("nan"), device=rt.device)
+    rt.call("msc_conv2d_wgrad", xd, dyd, dw2, ws, wsb, Bc, Hc, Wc, C, C, 3, 3, 1, 1, 0, rt.dt)
+    acc = outs[1].clone()
+    rt.call("msc_conv2d_wgrad", xd, dyd, acc, ws, wsb, Bc, Hc, Wc, C, C, 3, 3, 1, 1, 1, rt.dt)
     torch.cuda.synchronize()
     assert torch.equal(dw2, outs[1])
     check("accumulate", acc, 2 * ref, 2e-3)
