@@ -37,7 +37,7 @@ PMC_HBM_SUMMARY = "profiles/r4_pmc_hbm_bench_c3.csv"
 def gemm_source_sha():
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm_pp.hip", "gemm_skinny.hip", "conv_c64.hip", "gemm_plan.h"):        # the kernels and their launch planning (tile choice, split counts)
+    for f in ("gemm.hip", "gemm_pp.hip", "gemm_skinny.hip", "conv_c64.hip", "conv_c64w.hip", "conv_stem.hip", "gemm_plan.h"):        # the kernels and their launch planning (tile choice, split counts)
         h.update(open(os.path.join(ROOT, "multimodal_sc_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -58,7 +58,7 @@ def pmc_hbm_bytes_per_gemm_launch(n_launches_instrumented=0):
         return None, f"{PMC_HBM_SUMMARY} is stale (csrc/gemm.hip or gemm_plan.h changed since the PMC pass)"
     b = n = 0.0
     for r in csv.DictReader(open(path)):
-        if any(k in r["kernel"] for k in ("gemm_kernel<unsigned short", "gemm_pp_kernel<", "gemm_skinny_kernel<", "conv_c64_kernel<")):
+        if any(k in r["kernel"] for k in ("gemm_kernel<unsigned short", "gemm_pp_kernel<", "gemm_skinny_kernel<", "conv_c64_kernel<", "conv_c64_wgrad_kernel", "stem_wgrad_kernel")):
             b += float(r["fetch_bytes_corrected_x2"]) + float(r["write_bytes"])
             n += int(r["calls"])
     # The profiled run is the normal multi-stream step, where the fusion layers launch every dense GEMM twice (two half-batch
@@ -527,7 +527,7 @@ def main(argv=None):
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                               "traffic_source": traffic_src, "algorithmic_bytes_per_launch": gemm_b / max(n_gemm, 1),
-                              "kernel": "gemm_kernel<bf16,*> + gemm_pp_kernel<*> + conv_c64_kernel<*> + gemm_skinny_kernel<*> (the MFMA contraction kernels: convolutions, linears)",
+                              "kernel": "gemm_kernel<bf16,*> + gemm_pp_kernel<*> + conv_c64_kernel<*> + conv_c64_wgrad_kernel + stem_wgrad_kernel + gemm_skinny_kernel<*> (the MFMA contraction kernels: convolutions, linears)",
                               "launches_per_step": n_gemm, "algorithmic_gflop_per_step": gemm_f / 1e9, "kernel_ms_per_step": gemm_t,
                               # the same FLOPs over the WHOLE timed step (checkable against the driver's clock around the run):
                               # what the step sees, with every other kernel, the stream overlap and the host loop included

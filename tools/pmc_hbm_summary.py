@@ -31,7 +31,7 @@ if len(sys.argv) > 3:
     out.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm_pp.hip", "gemm_skinny.hip", "conv_c64.hip", "gemm_plan.h"):       # the same list as bench.gemm_source_sha
+    for f in ("gemm.hip", "gemm_pp.hip", "gemm_skinny.hip", "conv_c64.hip", "conv_c64w.hip", "conv_stem.hip", "gemm_plan.h"):       # the same list as bench.gemm_source_sha
         h.update(open(os.path.join(root, "multimodal_sc_amd", "csrc", f), "rb").read())
     sha = h.hexdigest()[:16]
     # steps the profiled command ran (warm-up + timed): PMC_STEPS, default 4 = `bench.py --steps 3 --warmup 1` of tools/round_profile.sh

@@ -7,7 +7,7 @@ prints them beside kernel_ms_per_pass of the bench line."""
 import csv, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 passes = int(sys.argv[2])
-gk = lambda n: any(k in n for k in ("gemm_kernel", "gemm_pp_kernel", "gemm_skinny_kernel", "conv_c64_kernel"))
+gk = lambda n: any(k in n for k in ("gemm_kernel", "gemm_pp_kernel", "gemm_skinny_kernel", "conv_c64_kernel", "conv_c64_wgrad_kernel", "stem_wgrad_kernel"))
 fam = lambda n: gk(n) or ("splitk_reduce_kernel" in n) or ("splitk_finish_kernel" in n)
 tot = sum(float(r["TotalDurationNs"]) for r in rows if fam(r["Name"]))
 calls = sum(int(r["Calls"]) for r in rows if fam(r["Name"]))
