@@ -17,6 +17,7 @@
 //   * at the end each workgroup stores its 64 x 256 fp32 partial; the split-K reduce of gemm.hip sums them in workgroup order.
 #include "msc_common.h"
 #include "gemm_plan.h"
+#include <type_traits>
 
 namespace {
 
@@ -155,6 +156,159 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const SWParams p) {
       for (int r = 0; r < 4; ++r) out[(16 * j + 4 * g + r) * 256 + (wave * 4 + kw) * 16 + (lane & 15)] = acc[j][kw][r];
 }
 
+// ================================================================================================ forward
+// y[p][co] = sum over the 4 x 4 taps and 16 channels of xs[p + (kh - 2, kw - 2)][c] * w[co][kh][kw][c] (+ per-tile BatchNorm partial sums).  As an
+// implicit GEMM (M = 802 816 pixels, N = 64, K = 256) it was 77 us for 26 GFLOP, every pixel's 32 bytes gathered sixteen times.  Scheme of
+// conv_c64.hip: the wave's 32 x 256 weight block in 64 registers for the whole kernel, the tile's halo staged once (the same 5 x 115-pixel halo
+// as the weight gradient above), v_mfma_f32_16x16x32_bf16 issued transposed with permuted weight rows (a lane stores 8 consecutive channels).
+// A k-step is two taps x 16 channels: lane group lg reads tap 2 ks + (lg >> 1), channels 8 (lg & 1) .. + 7 of its pixel — one ds_read_b128 at
+// base(pixel, lg) + a per-k-step immediate (the halo has no swizzle: 32-byte pixels, 2-way bank conflicts accepted).
+constexpr int SF_NF = SW_PIX / 16, SF_FW = SF_NF / 2;     // 14 pixel fragments per tile, 7 per wave
+constexpr int SF_KS = 8;                                  // k-steps of 32 = 2 taps x 16 channels
+
+struct SFParams {
+  const void* xs; const void* w; void* y;
+  float* part; int part_rows;                             // [part_rows][2][64]
+  int B, H;
+};
+
+typedef __attribute__((ext_vector_type(4))) uint32_t sw_u32x4;
+
+__device__ __forceinline__ float sf_row_sum(float v) {
+  auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});
+  v += dpp(v, std::integral_constant<int, 0x4E>{});
+  v += dpp(v, std::integral_constant<int, 0x124>{});
+  v += dpp(v, std::integral_constant<int, 0x128>{});
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const SFParams p) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * SW_HALO_BYTES];
+  __shared__ float red[2][2][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_per_img = p.H / SW_R;
+  const int ntiles = p.B * tiles_per_img;
+
+  // ---- halo DMA (as in the weight-gradient kernel)
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.xs) - (2 * SW_W + 2) * 32), 0, (int)0x7ffffff0, 0x00020000);
+  constexpr int NHW = (SW_NH + 3) / 4;
+  uint32_t hrel[NHW];
+  int hrow[NHW];
+#pragma unroll
+  for (int i = 0; i < NHW; ++i) {
+    const int s = 64 * (wave + 4 * i) + lane;
+    const int P = s >> 1, hr = P / SW_HW, hc = P - hr * SW_HW;
+    const bool ok = P < SW_HPIX && hc >= 2 && hc < SW_W + 2;
+    hrel[i] = ok ? (uint32_t)((hr * SW_W + hc) * 32 + (s & 1) * 16) : SW_OOB;
+    hrow[i] = hr;
+  }
+  auto stage = [&](int tile, int buf) __attribute__((always_inline)) {
+    const int b = tile / tiles_per_img, r0 = (tile - b * tiles_per_img) * SW_R;
+    const uint32_t pix0 = (uint32_t)((b * p.H + r0) * SW_W);
+#pragma unroll
+    for (int i = 0; i < NHW; ++i) {
+      if (wave + 4 * i < SW_NH) {
+        const int row = r0 - 2 + hrow[i];
+        const bool dead = row < 0 || row >= p.H;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, SW_LDS(lds + buf * SW_HALO_BYTES + (wave + 4 * i) * 1024), 16, dead ? SW_OOB : hrel[i], pix0 * 32u, 0, 0);
+      }
+    }
+  };
+  int tile = (int)blockIdx.x;
+  if (tile < ntiles) stage(tile, 0);
+
+  // ---- weights -> registers: MFMA row i of channel fragment j <- channel 32 wn + 8 (i >> 2) + 4 j + (i & 3)
+  sw_bf16x8 wreg[2][SF_KS];
+  {
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = 32 * wn + 8 * (lr >> 2) + 4 * j + (lr & 3);
+#pragma unroll
+      for (int ks = 0; ks < SF_KS; ++ks) wreg[j][ks] = *reinterpret_cast<const sw_bf16x8*>(W + ch * 256 + ks * 32 + 8 * lg);
+    }
+  }
+  // ---- pixel fragment bases: pixel q = 16 (7 wm + f) + lr -> halo byte ((q / 112) * 115 + q % 112) * 32 + 16 lg  (tap (0, 0); + (kh * 115 + kw) * 32 per k-step)
+  uint32_t fbase[SF_FW];
+#pragma unroll
+  for (int f = 0; f < SF_FW; ++f) {
+    const int q = 16 * (SF_FW * wm + f) + lr;
+    const int r = q / SW_W, c = q - r * SW_W;
+    fbase[f] = (uint32_t)((r * SW_HW + c) * 32 + 16 * lg);
+  }
+  const uint32_t out_lane = (uint32_t)(32 * wn + 8 * lg) * 2u;
+
+  int buf = 0;
+  bool first = true;
+  for (; tile < ntiles; tile += (int)gridDim.x, buf ^= 1) {
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");          // the previous tile's 7 (+1) stores may stay in flight: the halo DMA is older
+    first = false;
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) stage(tile + (int)gridDim.x, buf ^ 1);
+    const char* img = lds + buf * SW_HALO_BYTES;
+
+    sw_f32x4 acc[SF_FW][2];
+#pragma unroll
+    for (int f = 0; f < SF_FW; ++f) { acc[f][0] = sw_f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = sw_f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < SF_KS; ++ks) {
+      const int koff = ((ks >> 1) * SW_HW + 2 * (ks & 1)) * 32;      // taps (kh = ks >> 1, kw = 2 (ks & 1) + (lg >> 1))
+#pragma unroll
+      for (int f = 0; f < SF_FW; ++f) {
+        const sw_bf16x8 xf = *reinterpret_cast<const sw_bf16x8*>(img + fbase[f] + koff);
+        acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[0][ks], xf, acc[f][0], 0, 0, 0);
+        acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[1][ks], xf, acc[f][1], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: the lane holds channels 32 wn + 8 lg .. + 7 of pixel 16 (7 wm + f) + lr
+    const int b = tile / tiles_per_img, r0 = (tile - b * tiles_per_img) * SW_R;
+    const long pix0 = ((long)b * p.H + r0) * SW_W;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int f = 0; f < SF_FW; ++f) {
+      const long o = (pix0 + 16 * (SF_FW * wm + f) + lr) * 128 + out_lane;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[f][0][e]; v[4 + e] = acc[f][1][e]; }
+      if (p.part) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+      }
+      sw_u32x4 wv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wv[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+      *reinterpret_cast<sw_u32x4*>(reinterpret_cast<char*>(p.y) + o) = wv;
+    }
+    if (p.part) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] = sf_row_sum(s1[e]); s2[e] = sf_row_sum(s2[e]); }
+      if (lr == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[wm][0][32 * wn + 8 * lg + e] = s1[e]; red[wm][1][32 * wn + 8 * lg + e] = s2[e]; }
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int st = tid >> 6, ch = tid & 63;
+        p.part[(long)tile * 128 + st * 64 + ch] = red[0][st][ch] + red[1][st][ch];
+      }
+    }
+  }
+  if (p.part) {       // rows of the caller's partial buffer this kernel has no tile for: zero (msc_bn_finalize sums every row)
+    const long n0 = (long)ntiles * 128, n1 = (long)p.part_rows * 128;
+    for (long i = n0 + (long)blockIdx.x * 256 + tid; i < n1; i += (long)gridDim.x * 256) p.part[i] = 0.f;
+  }
+}
+
 }  // namespace
 
 bool msc_stem_wgrad_halo_ok(int B, int Hs, int Ws, int Cout, int dtype, int64_t ws_bytes) {
@@ -175,4 +329,21 @@ int msc_stem_wgrad_halo_launch(const void* xs, const void* dy, float* slab, int6
   p.xs = xs; p.dy = dy; p.slab = slab; p.B = B; p.H = Hs;
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
   return msc_launch_status() == MSC_OK ? (int)nwg : -MSC_ERR_LAUNCH;
+}
+
+bool msc_stem_fwd_halo_ok(int B, int Hs, int Ws, int Cout, int dtype) {
+  if (!mscplan::g_knobs.stem_fwd_halo || mscplan::g_knobs.tile_bm) return false;
+  if (dtype != MSC_BF16 || Cout != 64 || Ws != SW_W || Hs % SW_R || Hs < SW_R || B < 1) return false;
+  return (long)B * Hs * Ws * 128 < 0x7ffffff0L;
+}
+
+int msc_stem_fwd_halo_launch(const void* xs, const void* w, void* y, float* part, int part_rows, int B, int Hs, int ncu, hipStream_t st) {
+  if ((((uintptr_t)xs | (uintptr_t)w | (uintptr_t)y) & 15) != 0) return MSC_ERR_BAD_ARG;
+  const int ntiles = B * (Hs / SW_R);
+  if (part && part_rows < ntiles) return MSC_ERR_BAD_ARG;
+  SFParams p;
+  p.xs = xs; p.w = w; p.y = y; p.part = part; p.part_rows = part_rows; p.B = B; p.H = Hs;
+  const int nwg = ntiles < 2 * ncu ? ntiles : 2 * ncu;      // two workgroups per CU (36 KB of LDS, <= 128 registers each)
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  return msc_launch_status();
 }

@@ -1193,7 +1193,9 @@ int msc_pp_launch(const GemmParams& p, int ncu, hipStream_t st);
 bool msc_conv_c64_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype);      // conv_c64.hip: ResNet layer 1
 int msc_conv_c64_launch(const void* x, const void* w, void* y, const void* res, const void* relu_ref, float* part, int part_rows, int B, int H,
                         int flip, int ncu, hipStream_t st);
-bool msc_stem_wgrad_halo_ok(int B, int Hs, int Ws, int Cout, int dtype, int64_t ws_bytes);      // conv_stem.hip
+bool msc_stem_fwd_halo_ok(int B, int Hs, int Ws, int Cout, int dtype);                           // conv_stem.hip
+int msc_stem_fwd_halo_launch(const void* xs, const void* w, void* y, float* part, int part_rows, int B, int Hs, int ncu, hipStream_t st);
+bool msc_stem_wgrad_halo_ok(int B, int Hs, int Ws, int Cout, int dtype, int64_t ws_bytes);
 int msc_stem_wgrad_halo_launch(const void* xs, const void* dy, float* slab, int64_t slab_bytes, int B, int Hs, int ncu, hipStream_t st);
 bool msc_conv_c64_wgrad_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype, int64_t ws_bytes);      // conv_c64w.hip
 int64_t msc_conv_c64_wgrad_workspace_bytes(int ncu);
@@ -1465,6 +1467,11 @@ extern "C" int msc_stem_s2d_conv_fwd(const void* xs, const void* w_s2d, void* y,
   MSC_CHECK_ARG(xs && w_s2d && y && B > 0 && Hs > 0 && Ws > 0 && Cout > 0);
   MSC_CHECK_ARG(dtype == MSC_F32 || dtype == MSC_BF16);
   if (!fits32((long)B * Hs * Ws * 16, dtype)) return MSC_ERR_UNSUPPORTED;
+  if (msc_stem_fwd_halo_ok(B, Hs, Ws, Cout, dtype)) {      // halo staged once, weights in registers: conv_stem.hip
+    note_gemm(8, 224, 64, 256, 1, 0, 0, 0);
+    return msc_stem_fwd_halo_launch(xs, w_s2d, y, bn_partial, bn_partial ? (int)msc_conv2d_fwd_stat_rows((int64_t)B * Hs * Ws, Cout, dtype) : 0, B, Hs, num_cus(),
+                                    (hipStream_t)stream);
+  }
   GemmParams p = base_params();
   p.A = xs; p.B = w_s2d; p.C = y; p.stats = bn_partial;
   p.M = B * Hs * Ws; p.N = Cout; p.K = 256;

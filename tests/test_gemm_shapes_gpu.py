@@ -547,3 +547,41 @@ def test_conv_c64_wgrad(rt, knob, Bc, Hc):
     torch.cuda.synchronize()
     assert torch.equal(dw2, outs[1])
     check("accumulate", acc, 2 * ref, 2e-3)
+
+
+@pytest.mark.parametrize("Bs,Hs", [(2, 112), (1, 2), (3, 6), (64, 112)])
+def test_stem_fwd_halo(rt, knob, Bs, Hs):
+    """forward of the space-to-depth stem (4x4 / stride 1, pad 2 before / 1 after, 16 -> 64 channels on 112-wide maps) through conv_stem.hip (halo staged
+    once, weights in registers): output and BatchNorm partial sums against fp32 PyTorch from bf16-rounded inputs, against the implicit-GEMM
+    kernel, bit-identical when repeated"""
+    from multimodal_sc_amd import lib as L
+    Ws, Cout = 112, 64
+    xs = rnd(Bs, Hs, Ws, 16, seed=1)
+    w = rnd(Cout, 4, 4, 16, seed=2, scale=1 / 16.0)
+    xin = TF.pad(qb(xs).permute(0, 3, 1, 2), (2, 1, 2, 1))
+    ref = TF.conv2d(xin, qb(w).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    rows = Bs * Hs * Ws
+    nblk = L.query("msc_conv2d_fwd_stat_rows", rows, Cout, rt.dt)
+    xd, wd = dev(xs, rt), dev(w, rt)
+    outs = {}
+    for on in (1, 0):
+        knob("stem_fwd_halo", on)
+        y = torch.full((Bs, Hs, Ws, Cout), float("nan"), device=rt.device, dtype=rt.tdtype)
+        part = torch.full((nblk, 2, Cout), float("nan"), device=rt.device)
+        rt.call("msc_stem_s2d_conv_fwd", xd, wd, y, part, Bs, Hs, Ws, Cout, rt.dt)
+        info = last_gemm()
+        assert (info[0] == 8) == bool(on), info
+        check(f"y halo={on}", y, ref, 1.2e-2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        s = part.double().sum(0).cpu()
+        flat = ref.reshape(-1, Cout).double()
+        assert (s[0] - flat.sum(0)).abs().max() <= 2e-3 * max(1.0, flat.abs().sum(0).max().item())
+        assert (s[1] - (flat * flat).sum(0)).abs().max() <= 2e-3 * max(1.0, (flat * flat).sum(0).max().item())
+        outs[on] = (y, part.clone())
+    check("halo vs implicit GEMM", outs[1][0], outs[0][0].float(), 1.2e-2)
+    knob("stem_fwd_halo", 1)
+    y2, part2 = torch.empty_like(outs[1][0]), torch.empty_like(outs[1][1])
+    rt.call("msc_stem_s2d_conv_fwd", xd, wd, y2, part2, Bs, Hs, Ws, Cout, rt.dt)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, outs[1][0]) and torch.equal(part2, outs[1][1])
