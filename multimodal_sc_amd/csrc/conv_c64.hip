@@ -369,7 +369,12 @@ int msc_conv_c64_launch(const void* x, const void* w, void* y, const void* res, 
   p.x = x; p.w = w; p.y = y; p.res = res; p.relu_ref = relu_ref; p.part = part; p.part_rows = part_rows; p.B = B; p.H = H; p.flip = flip;
   const int ntiles = B * (H / C6_TR);
   if (part && part_rows < ntiles) return MSC_ERR_BAD_ARG;
-  const dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu));
+  // Workgroups: the smallest count that needs no more rounds of tiles than one per CU would (64 frames: 896 tiles = 4 rounds on 256 CUs, 3.5 tiles
+  // each; on 224 workgroups 4 tiles each — the same time, and 32 CUs stay free for whatever runs beside the launch).  knob c64_wgs overrides.
+  int nwg = ntiles < ncu ? ntiles : ncu;
+  if (mscplan::g_knobs.c64_wgs > 0) nwg = mscplan::g_knobs.c64_wgs < nwg ? mscplan::g_knobs.c64_wgs : nwg;
+  else if (nwg == ncu) { const int rounds = (ntiles + ncu - 1) / ncu; nwg = (ntiles + rounds - 1) / rounds; }
+  const dim3 grid((unsigned)nwg);
   if (flip) hipLaunchKernelGGL(conv_c64_kernel<1>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(conv_c64_kernel<0>, grid, dim3(256), 0, st, p);
   return msc_launch_status();

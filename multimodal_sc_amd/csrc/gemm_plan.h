@@ -55,6 +55,7 @@ struct Knobs {
   int dgrad_cls_interleave = 1;      // dgrad_cls_interleave: parity classes of a strided dgrad interleaved in launch order
   int gemm_pp = 1;                   // gemm_pp: dense bf16 linears on the persistent ping-pong kernel (gemm_pp.hip); 256/192/160: tile rows forced
   int gemm_pp_k = 0;                 // gemm_pp_k: (bisecting aid) only contractions of this reduction length take the ping-pong kernel; 0 = any
+  int c64_wgs = 0;                   // c64_wgs: workgroups of the layer-1 forward / data-gradient kernel (0: fewest that keep the round count of one per CU)
   int stem_fwd_halo = 1;             // stem_fwd_halo: the stem's forward convolution on the halo-resident kernel of conv_stem.hip (0: implicit GEMM)
   int c64w_wgs = 0;                  // c64w_wgs: workgroups of the layer-1 weight-gradient kernel (0: half the CUs; -1: the gathered split-K GEMM instead)
   int stem_wgrad_halo = 1;           // stem_wgrad_halo: the stem's weight gradient on the halo-resident kernel of conv_stem.hip (0: gathered split-K GEMM)
@@ -91,6 +92,7 @@ static inline Knobs knobs_from_env() {
   k.stem_wgrad_halo = (int)knob_env("MSC_STEM_WGRAD_HALO", 1);
   k.c64w_wgs = (int)knob_env("MSC_C64W_WGS", 0);
   k.stem_fwd_halo = (int)knob_env("MSC_STEM_FWD_HALO", 1);
+  k.c64_wgs = (int)knob_env("MSC_C64_WGS", 0);
   k.gemm_pp_k = (int)knob_env("MSC_GEMM_PP_K", 0);
   k.att_bwd_waves = (int)knob_env("MSC_ATT_BWD_WAVES", 0);
   k.att_dq_waves = (int)knob_env("MSC_ATT_DQ_WAVES", 0);
@@ -117,6 +119,7 @@ static inline long* knob_slot(const char* name, int*& as_int) {
   else if (!strcmp(name, "stem_wgrad_halo")) as_int = &k.stem_wgrad_halo;
   else if (!strcmp(name, "c64w_wgs")) as_int = &k.c64w_wgs;
   else if (!strcmp(name, "stem_fwd_halo")) as_int = &k.stem_fwd_halo;
+  else if (!strcmp(name, "c64_wgs")) as_int = &k.c64_wgs;
   else if (!strcmp(name, "gemm_pp_k")) as_int = &k.gemm_pp_k;
   else if (!strcmp(name, "att_bwd_waves")) as_int = &k.att_bwd_waves;
   else if (!strcmp(name, "att_dq_waves")) as_int = &k.att_dq_waves;
