@@ -332,7 +332,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) w[e] = pp_pack2(v[2 * e], v[2 * e + 1]);
       __builtin_amdgcn_raw_buffer_store_b128(w, rsC, off, 0, 2);
-      if constexpr (ACT == MSC_ACT_GELU_DSAVE) __builtin_amdgcn_sched_barrier(0);     // one fragment's erf arithmetic at a time (registers)
+      // (256-row tiles: one fragment's erf arithmetic at a time — registers; the smaller tiles let the compiler interleave fragments: fc1 -3 %)
+      if constexpr (ACT == MSC_ACT_GELU_DSAVE && MI > 6) __builtin_amdgcn_sched_barrier(0);
     }
   };
   // vector-memory instructions one fragment of an epilogue issues and leaves in flight (its loads are consumed inside): the stores
