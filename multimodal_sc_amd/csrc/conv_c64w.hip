@@ -173,6 +173,7 @@ int msc_conv_c64_wgrad_launch(const void* x, const void* dy, float* slab, int64_
   long nwg = ntiles < ncu ? ntiles : ncu;
   const long room = slab_bytes / ((long)64 * 576 * 4);
   if (nwg > room) nwg = room;
+  if (nwg > 0) { const long rounds = (ntiles + nwg - 1) / nwg; nwg = (ntiles + rounds - 1) / rounds; }     // fewest workgroups for that many rounds of tiles (32 frames: 112 x 4 instead of 128 x 3.5)
   CWParams p;
   p.x = x; p.dy = dy; p.slab = slab; p.B = B; p.H = H;
   hipLaunchKernelGGL(conv_c64_wgrad_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);

@@ -325,6 +325,7 @@ int msc_stem_wgrad_halo_launch(const void* xs, const void* dy, float* slab, int6
   long nwg = ntiles < ncu ? ntiles : ncu;
   const long room = slab_bytes / ((long)64 * 256 * 4);
   if (nwg > room) nwg = room;
+  if (nwg > 0) { const long rounds = (ntiles + nwg - 1) / nwg; nwg = (ntiles + rounds - 1) / rounds; }     // fewest workgroups for that many rounds of tiles
   SWParams p;
   p.xs = xs; p.dy = dy; p.slab = slab; p.B = B; p.H = Hs;
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
