@@ -53,7 +53,7 @@ struct Knobs {
   long wgrad_small_max = 512;        // wgrad_small_max
   int wgrad_xcd_split = 1;           // wgrad_xcd_split: pin every K slice of a weight gradient to one XCD
   int dgrad_cls_interleave = 1;      // dgrad_cls_interleave: parity classes of a strided dgrad interleaved in launch order
-  int gemm_pp = 1;                   // gemm_pp: dense bf16 linears on the persistent ping-pong kernel (gemm_pp.hip); 256/192/160: tile rows forced
+  int gemm_pp = 1;                   // gemm_pp: dense bf16 linears on the persistent ping-pong kernel (gemm_pp.hip); 256/192/160/128: tile rows forced
   int gemm_pp_k = 0;                 // gemm_pp_k: (bisecting aid) only contractions of this reduction length take the ping-pong kernel; 0 = any
   int c64_wgs = 0;                   // c64_wgs: workgroups of the layer-1 forward / data-gradient kernel (0: fewest that keep the round count of one per CU)
   int stem_fwd_halo = 1;             // stem_fwd_halo: the stem's forward convolution on the halo-resident kernel of conv_stem.hip (0: implicit GEMM)

@@ -500,6 +500,7 @@ template <int EPI, int ACT> int launch_pp_epi(const GemmParams& p, int bm, hipSt
   if (bm == 256) hipLaunchKernelGGL((gemm_pp_kernel<4, 4, EPI, ACT>), grid, dim3(512), 0, st, p);
   else if (bm == 192) hipLaunchKernelGGL((gemm_pp_kernel<3, 3, EPI, ACT>), grid, dim3(512), 0, st, p);
   else if (bm == 160) hipLaunchKernelGGL((gemm_pp_kernel<3, 2, EPI, ACT>), grid, dim3(512), 0, st, p);
+  else if (bm == 128) hipLaunchKernelGGL((gemm_pp_kernel<2, 2, EPI, ACT>), grid, dim3(512), 0, st, p);
   else return MSC_ERR_UNSUPPORTED;
   return msc_launch_status();
 }
@@ -528,13 +529,15 @@ int msc_pp_tile_rows(const GemmParams& p, int ncu) {
   // Tile height: 256 rows (128 FLOP per staged byte), 192 (110) or 160 (98): whichever needs least time for ceil(tiles / CUs) rounds of
   // tiles, a round costing its tile's rows (+ a fixed share for the per-tile epilogue / refill).  On the path's 19584-row linears that is
   // 160 everywhere (246 tiles for 512 output columns = one round on 256 CUs; measured 346 vs 386 (192) vs 431 us (256) per block);
-  // large square contractions take 256 (8192 x 8192 x 4096: 1.36 PFLOP/s vs 1.11 / 1.04).  knob gemm_pp: 1 = this rule; 256 / 192 / 160
-  // = that height forced.
+  // large square contractions take 256 (8192 x 8192 x 4096: 1.36 PFLOP/s vs 1.11 / 1.04).  128 rows (85 FLOP per staged byte) only ever wins
+  // where the taller tiles leave CUs without a tile: the 512-column linears of a 32-frame shard (9792 rows: 124 tiles of 160 rows on 256 CUs,
+  // 154 of 128 rows — BASELINE.json configs[3]'s per-GPU geometry); at 64 frames the rule never picks it.  knob gemm_pp: 1 = this rule;
+  // 256 / 192 / 160 / 128 = that height forced.
   const int forced = mscplan::g_knobs.gemm_pp;
-  if (forced == 256 || forced == 192 || forced == 160) return forced;
+  if (forced == 256 || forced == 192 || forced == 160 || forced == 128) return forced;
   const long ntn = p.N / 256;
   long best = 0, best_cost = 0;
-  for (long bm : {256L, 192L, 160L}) {
+  for (long bm : {256L, 192L, 160L, 128L}) {
     const long rounds = mscplan::cdivl(mscplan::cdivl(p.M, bm) * ntn, ncu);
     const long cost = rounds * (bm + 24);
     if (!best || cost < best_cost) { best = bm; best_cost = cost; }

@@ -80,7 +80,7 @@ def test_fusion_linear_forward_at_benchmark_shape(rt, knob, name, N, K, rows, pp
         rt.call("msc_linear_fwd", dev(x, rt), dev(w, rt), b.to(rt.device), dev(r, rt) if res else None, y, None, rows, N, K, L.ACT_NONE, rt.dt)
     info = last_gemm()
     if pp:
-        assert info[0] == 3 and info[1] in ((160, 192, 256) if pp == 1 else (pp,)) and info[2:4] == (256, 512), info      # persistent ping-pong, 8 waves
+        assert info[0] == 3 and info[1] in ((128, 160, 192, 256) if pp == 1 else (pp,)) and info[2:4] == (256, 512), info      # persistent ping-pong, 8 waves
     else:
         assert info[0] == 1 and info[1:4] == (128, 128, 512), info          # one tile per workgroup, 128 x 128, 8 waves
     check("y", y, ref, 1.2e-2)
@@ -111,13 +111,13 @@ def test_fusion_linear_dgrad_at_benchmark_shape(rt, knob, name, N, K, pp):
             L.ACT_MUL_REF if dref is not None else L.ACT_NONE, None, dx, M, N, K, rt.dt)
     info = last_gemm()
     if pp:
-        assert info[0] == 3 and info[1] in (160, 192, 256) and info[2:4] == (256, 512), info
+        assert info[0] == 3 and info[1] in (128, 160, 192, 256) and info[2:4] == (256, 512), info
     else:
         assert info[0] == 1 and info[1:4] == (128, 128, 512), info
     check("dx", dx, ref, 2.4e-2)
 
 
-@pytest.mark.parametrize("bm", [160, 192, 256])
+@pytest.mark.parametrize("bm", [128, 160, 192, 256])
 @pytest.mark.parametrize("name,N,K", LINEARS)
 def test_ping_pong_kernel_bitwise_under_concurrent_load(rt, knob, name, N, K, bm):
     """The persistent ping-pong kernel keeps four LDS-DMA pieces and its epilogue stores in flight behind COUNTED waits: a count that

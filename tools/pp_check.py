@@ -62,7 +62,7 @@ for name, N, K in [("qkv", 1536, 512), ("proj", 512, 512), ("fc1", 2048, 512), (
         return g * dref.float() if dref is not None else g
     cases.append((f"dgrd {name:5s} out{K} red{N}", fl, dgrad, dgrad_ref, dx, (lambda dy=dy, wt=wt: torch.matmul(dy, wt.t()))))
 
-MODES = [("pp", 1), ("pp160", 160), ("pp192", 192), ("pp256", 256), ("tiled", 0)]      # knob gemm_pp: 1 = planner's tile height
+MODES = [("pp", 1), ("pp128", 128), ("pp160", 160), ("pp192", 192), ("pp256", 256), ("tiled", 0)]      # knob gemm_pp: 1 = planner's tile height
 tot = {k: 0.0 for k, _ in MODES}
 tot["vendor"] = 0.0
 for name, fl, fn, ref_fn, out, vend in cases:
