@@ -48,7 +48,7 @@ struct Knobs {
   int tile_bm = 0, tile_bn = 0;      // gemm_tile: force a tile (value = bm * 1000 + bn; 0 = planner's choice)          MSC_GEMM_TILE=BMxBN
   long t128 = 0;                     // gemm_t128: workgroup count below which a 128-wide tile shrinks to 64 (0 = default)
   int conv_splitk = 1;               // conv_splitk: split-K for chip-underfilling conv forward / stride-1 dgrad launches
-  long wgrad_blocks = 640;           // wgrad_blocks: workgroup target of the weight-gradient K split
+  long wgrad_blocks = 512;           // wgrad_blocks: workgroup target of the weight-gradient K split
   int wgrad_small = 1;               // wgrad_small: short K slices for outputs of 1-8 tiles
   long wgrad_small_max = 512;        // wgrad_small_max
   int wgrad_xcd_split = 1;           // wgrad_xcd_split: pin every K slice of a weight gradient to one XCD
@@ -78,8 +78,8 @@ static inline Knobs knobs_from_env() {
   }
   k.t128 = knob_env("MSC_GEMM_T128", 0);
   k.conv_splitk = (int)knob_env("MSC_CONV_SPLITK", 1);
-  k.wgrad_blocks = knob_env("MSC_WGRAD_BLOCKS", 640);
-  if (k.wgrad_blocks < 1) k.wgrad_blocks = 640;
+  k.wgrad_blocks = knob_env("MSC_WGRAD_BLOCKS", 512);
+  if (k.wgrad_blocks < 1) k.wgrad_blocks = 512;
   k.wgrad_small = (int)knob_env("MSC_WGRAD_SMALL", 1);
   k.wgrad_small_max = knob_env("MSC_WGRAD_SMALL_MAX", 512);
   k.wgrad_xcd_split = (int)knob_env("MSC_WGRAD_XCD_SPLIT", 1);
@@ -211,10 +211,12 @@ static inline ConvSplit conv_split(long M, long N, long k_len, int dtype_is_f32)
 // split-K of the weight-gradient GEMMs (output rows_out x cols_out, reduction over reduce_len pixels / tokens)
 static inline int plan_split(long rows_out, long cols_out, long reduce_len) {
   const long tiles = cdivl(rows_out, 128) * cdivl(cols_out, cols_out <= 64 ? 64 : 128);
-  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it; ~640 workgroups measured best
-  // (fewer: underfilled when the main stream idles; more: fp32 slab traffic = nsplit x output).  Same-box sweep of the step
-  // at the end of round 2 (XCD pinning really applied, fusion as two chains): 384: +0.09 ms, 512: +0.05, 640: 0, 768: +0.07.
-  const long target = g_knobs.wgrad_blocks > 0 ? g_knobs.wgrad_blocks : 640;
+  // weight gradients run on a side stream beside the dgrad chain, and share the chip with it (fewer workgroups: underfilled when the
+  // main stream idles; more: fp32 slab traffic = nsplit x output).  Same-box sweep of the step at the end of round 2 (XCD pinning really
+  // applied, fusion as two chains): 384: +0.09 ms, 512: +0.05, 640: 0, 768: +0.07.  End of round 4 (fusion as one chain on the ping-pong
+  // kernel, halo kernels for layer 1 and the stem): 512 beats 640 in every interleaved pair — 7.130 / 7.126 / 7.152 against 7.149 / 7.165 /
+  // 7.182 ms at 64 frames, 448 and 576 in between or worse, 32 frames -0.01 ms (profiles/r4_wgrad_blocks_512.txt).
+  const long target = g_knobs.wgrad_blocks > 0 ? g_knobs.wgrad_blocks : 512;
   long want = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
   // A slice is a SERIAL K loop of one workgroup.  Outputs of one to four tiles (1x1 downsample convolutions: 16 workgroups x 25 steps ran
   // 50 us for 0.8 GFLOP; the stem: 256 workgroups x 98 steps, 150 us, the last kernel of the backward) are latency-bound on that

@@ -532,7 +532,8 @@ int msc_pp_tile_rows(const GemmParams& p, int ncu) {
   // large square contractions take 256 (8192 x 8192 x 4096: 1.36 PFLOP/s vs 1.11 / 1.04).  128 rows (85 FLOP per staged byte) only ever wins
   // where the taller tiles leave CUs without a tile: the 512-column linears of a 32-frame shard (9792 rows: 124 tiles of 160 rows on 256 CUs,
   // 154 of 128 rows — BASELINE.json configs[3]'s per-GPU geometry); at 64 frames the rule never picks it.  knob gemm_pp: 1 = this rule;
-  // 256 / 192 / 160 / 128 = that height forced.
+  // 256 / 192 / 160 / 128 = that height forced.  (128 rows for the two epilogue-heavy launches only — fc1 forward, fc2's dgrad; isolated 55 vs 59 us for
+  // the latter — is +-0 inside the 64-frame step: profiles/r4_pp128_tile.txt.)
   const int forced = mscplan::g_knobs.gemm_pp;
   if (forced == 256 || forced == 192 || forced == 160 || forced == 128) return forced;
   const long ntn = p.N / 256;
