@@ -36,6 +36,17 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+// Transposed LDS read issued as inline assembly.  Through the builtin the compiler sees an LDS load it cannot prove independent of the
+// LDS-DMA writes in flight and places s_waitcnt vmcnt(0) in front of the first one of a K step — i.e. behind the prefetch of the NEXT
+// stage issued a few instructions earlier: DMA and MFMAs of the weight-gradient kernels ran one after the other (ISA of
+// gemm_kernel<bf16,1,1,128,128,...>, end of round 4).  The staged buffer being read was waited for explicitly (counted vmcnt + barrier)
+// at the top of the step, so no wait is needed here; the read's own completion is waited for by tr_wait().
+__device__ __forceinline__ s16x4_t ds_read_tr_asm(const char* lds_generic_ptr) {
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_generic_ptr;
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define DMA_OOB 0x80000000u   // >= num_records of every descriptor built here: the DMA writes zeros
 // K bytes per operand row per step (KB) and LDS ring depth are template parameters of the kernel; defaults per tile class
@@ -705,6 +716,11 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
 #pragma unroll
         for (int ks = 0; ks < KT / 16; ++ks) {
           mfma_bf16x8_t fa[MI], fb[NI];
+          s16x4_t alo[MI], ahi[MI], blo[NI], bhi[NI];      // halves of the transposed-read fragments (mn-major operands)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) { alo[i] = ahi[i] = s16x4_t{0, 0, 0, 0}; }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) { blo[j] = bhi[j] = s16x4_t{0, 0, 0, 0}; }
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             if constexpr (LA::KM) {
@@ -712,13 +728,8 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
             } else {
               const int col = wm * WM + i * 32 + 16 * (tg & 1) + 4 * tp;
               const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
-              s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                  As + k0r * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r)) << 4) + (tp & 1) * 8));
-              s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                  As + (k0r + 4) * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
-              typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-              s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-              fa[i] = __builtin_bit_cast(mfma_bf16x8_t, v);
+              alo[i] = ds_read_tr_asm(As + k0r * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r)) << 4) + (tp & 1) * 8);
+              ahi[i] = ds_read_tr_asm(As + (k0r + 4) * LA::ROWB + (((col >> 3) ^ mn_swz<LA::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8);
             }
           }
 #pragma unroll
@@ -728,14 +739,37 @@ __global__ __launch_bounds__(NTHR, (NTHR == 512 && (BM == 128 || !PERSIST) ? 4 :
             } else {
               const int col = wn * WN + j * 32 + 16 * (tg & 1) + 4 * tp;
               const int k0r = 16 * ks + 8 * (tg >> 1) + tq;
-              s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                  Bs + k0r * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r)) << 4) + (tp & 1) * 8));
-              s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
-                  Bs + (k0r + 4) * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8));
-              typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-              s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-              fb[j] = __builtin_bit_cast(mfma_bf16x8_t, v);
+              blo[j] = ds_read_tr_asm(Bs + k0r * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r)) << 4) + (tp & 1) * 8);
+              bhi[j] = ds_read_tr_asm(Bs + (k0r + 4) * LB::ROWB + (((col >> 3) ^ mn_swz<LB::ROWB>(k0r + 4)) << 4) + (tp & 1) * 8);
             }
+          }
+          // the assembly reads are invisible to the compiler's lgkmcnt bookkeeping: one wait for all of this sub-step's, tied to their
+          // registers so that nothing consuming them moves above it
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          if constexpr (!LA::KM) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+          }
+          if constexpr (!LB::KM) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+          }
+          if constexpr (!LA::KM || !LB::KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if constexpr (!LA::KM) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+          }
+          if constexpr (!LB::KM) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+          }
+          if constexpr (!LA::KM) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = __builtin_bit_cast(mfma_bf16x8_t, (s16x8_t)__builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+          if constexpr (!LB::KM) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[j] = __builtin_bit_cast(mfma_bf16x8_t, (s16x8_t)__builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7));
           }
 #pragma unroll
           for (int i = 0; i < MI; ++i)
