@@ -115,23 +115,50 @@ __global__ __launch_bounds__(256, 1) void conv_c64_wgrad_kernel(const CWParams p
     if (tile + (int)gridDim.x < ntiles) stage(tile + (int)gridDim.x, buf ^ 1);
     const char* himg = lds + buf * CW_BUF_BYTES;
     const char* dimg = himg + CW_HALO_BYTES;
-    auto tr = [&](const char* a0, const char* a1) __attribute__((always_inline)) {
-      const cw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cw_s16x4*)a0);
-      const cw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cw_s16x4*)a1);
+    // Transposed reads as inline assembly: through the builtin the compiler cannot prove the reads independent of the LDS-DMA writes of the
+    // NEXT tile issued just above and waits for them (s_waitcnt vmcnt(0)) before the first read — staging and MFMAs of a tile then run one
+    // after the other (the finding of csrc/gemm.hip ds_read_tr_asm).  The reads' own completion is waited for by hand: the operand of tap
+    // t + 1 is in flight under the MFMAs of tap t (lgkmcnt(2) = all but the two youngest reads), registers tied to the wait.
+    auto tr_issue = [&](cw_s16x4& lo, cw_s16x4& hi, const char* a0, const char* a1) __attribute__((always_inline)) {
+      const uint32_t u0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)a0;
+      const uint32_t u1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)a1;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(u0));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(u1));
+    };
+    auto join = [](const cw_s16x4& lo, const cw_s16x4& hi) __attribute__((always_inline)) {
       return __builtin_bit_cast(cw_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 #pragma unroll
     for (int ks = 0; ks < CW_KS; ++ks) {
-      cw_bf16x8 af[4];
+      cw_s16x4 alo[4], ahi[4], blo[2], bhi[2];
       const int q0 = qpix[ks][0], q1 = qpix[ks][1];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        af[j] = tr(dimg + q0 * 128 + ((j ^ cw_key(q0)) << 5) + 8 * pp, dimg + q1 * 128 + ((j ^ cw_key(q1)) << 5) + 8 * pp);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      auto issue_b = [&](int t) __attribute__((always_inline)) {
         const int toff = (t / 3 - 1) * CW_HW + (t % 3 - 1);
         const int P0 = hpix[ks][0] + toff, P1 = hpix[ks][1] + toff;
-        const cw_bf16x8 bf = tr(himg + P0 * 128 + ((wave ^ cw_key(P0)) << 5) + 8 * pp, himg + P1 * 128 + ((wave ^ cw_key(P1)) << 5) + 8 * pp);
+        tr_issue(blo[t & 1], bhi[t & 1], himg + P0 * 128 + ((wave ^ cw_key(P0)) << 5) + 8 * pp, himg + P1 * 128 + ((wave ^ cw_key(P1)) << 5) + 8 * pp);
+      };
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        tr_issue(alo[j], ahi[j], dimg + q0 * 128 + ((j ^ cw_key(q0)) << 5) + 8 * pp, dimg + q1 * 128 + ((j ^ cw_key(q1)) << 5) + 8 * pp);
+      issue_b(0);
+      cw_bf16x8 af[4];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t < 8) {
+          issue_b(t + 1);
+          asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        asm volatile("" : "+v"(blo[t & 1]), "+v"(bhi[t & 1]));
+        if (t == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            asm volatile("" : "+v"(alo[j]), "+v"(ahi[j]));
+            af[j] = join(alo[j], ahi[j]);
+          }
+        }
+        const cw_bf16x8 bf = join(blo[t & 1], bhi[t & 1]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bf, acc[j][t], 0, 0, 0);
       }

@@ -124,25 +124,45 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const SWParams p) {
     __syncthreads();                                      // ... for every wave; and nobody still reads the other buffer
     if (tile + (int)gridDim.x < ntiles) stage(tile + (int)gridDim.x, buf ^ 1);
     const char* img = lds + buf * SW_BUF_BYTES;
+    // Transposed reads as inline assembly (see csrc/gemm.hip ds_read_tr_asm: through the builtin the compiler waits for the NEXT tile's
+    // LDS-DMA, issued just above, before the first read — staging and MFMAs of a tile one after the other).  The reads' completion is waited
+    // for by hand: the halo operand of tap kw + 1 is in flight under the MFMAs of tap kw.
+    auto tr_issue = [&](sw_s16x4& lo, sw_s16x4& hi, const char* a0, const char* a1) __attribute__((always_inline)) {
+      const uint32_t u0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)a0;
+      const uint32_t u1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)a1;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(u0));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(u1));
+    };
+    auto join = [](const sw_s16x4& lo, const sw_s16x4& hi) __attribute__((always_inline)) {
+      return __builtin_bit_cast(sw_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
 #pragma unroll
     for (int ks = 0; ks < SW_KS; ++ks) {
-      sw_bf16x8 af[4], bf[4];
+      sw_s16x4 alo[4], ahi[4], blo[2], bhi[2];
+      sw_bf16x8 af[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const sw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sw_s16x4*)(img + abase[ks][0] + ((j ^ akey[ks][0]) << 5)));
-        const sw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sw_s16x4*)(img + abase[ks][1] + ((j ^ akey[ks][1]) << 5)));
-        af[j] = __builtin_bit_cast(sw_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
+      for (int j = 0; j < 4; ++j) tr_issue(alo[j], ahi[j], img + abase[ks][0] + ((j ^ akey[ks][0]) << 5), img + abase[ks][1] + ((j ^ akey[ks][1]) << 5));
+      tr_issue(blo[0], bhi[0], img + bbase[ks][0], img + bbase[ks][1]);
 #pragma unroll
       for (int kw = 0; kw < 4; ++kw) {
-        const sw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sw_s16x4*)(img + bbase[ks][0] + 32 * kw));
-        const sw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sw_s16x4*)(img + bbase[ks][1] + 32 * kw));
-        bf[kw] = __builtin_bit_cast(sw_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        if (kw < 3) {
+          tr_issue(blo[(kw + 1) & 1], bhi[(kw + 1) & 1], img + bbase[ks][0] + 32 * (kw + 1), img + bbase[ks][1] + 32 * (kw + 1));
+          asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        asm volatile("" : "+v"(blo[kw & 1]), "+v"(bhi[kw & 1]));
+        if (kw == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            asm volatile("" : "+v"(alo[j]), "+v"(ahi[j]));
+            af[j] = join(alo[j], ahi[j]);
+          }
+        }
+        const sw_bf16x8 bf = join(blo[kw & 1], bhi[kw & 1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bf, acc[j][kw], 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int kw = 0; kw < 4; ++kw) acc[j][kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bf[kw], acc[j][kw], 0, 0, 0);
     }
   }
 
